@@ -1,0 +1,143 @@
+/*
+ * kmerguts_hip.h -- C ABI of libkmerguts_hip.so, the MI355X (gfx950) implementation of the
+ * kmer_guts hot path of rsutormin/KmerGutsJava.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own (it is one Java class);
+ * every entry point below names the reference interface it replaces.  "KGJ:n" =
+ * lib/src/kmergutsjava/KmerGutsJava.java line n of the reference.  The Java (JNA) and Python
+ * (ctypes) bindings that call these are shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int status
+ * (KG_OK == 0, negative == error) and never throws or aborts across the boundary; the text
+ * of the last error on the calling thread is kg_last_error().  All memory returned by the
+ * library is owned by the library and released by kg_result_free / kg_table_close.
+ * A kg_table is read-only after creation and may be shared by host threads; at most one
+ * kg_scan* may be in flight per kg_table at a time (the reference's instance is not
+ * re-entrant either, KGJ:838).
+ */
+#ifndef KMERGUTS_HIP_H
+#define KMERGUTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KG_OK               0
+#define KG_ERR_ARG         (-1)   /* bad argument                                                  */
+#define KG_ERR_IO          (-2)   /* file could not be read                                        */
+#define KG_ERR_FORMAT      (-3)   /* table image malformed (short header, entrySize != 24, ...)    */
+#define KG_ERR_DEVICE      (-4)   /* HIP runtime error / no gfx950 device                          */
+#define KG_ERR_NOMEM       (-5)
+#define KG_ERR_UNSUPPORTED (-6)   /* parameters on which the reference itself throws (minHits < 2) */
+#define KG_ERR_LIMIT       (-7)   /* one call exceeds 2^32-1 windows or 2^31-1 window blocks       */
+
+/* KGJ:85-99 */
+#define KG_K                8
+#define KG_MAX_ENCODED      25600000000LL   /* 20^8; a table slot is empty iff whichKmer > this (KGJ:1000) */
+#define KG_MAX_HITS_PER_SEQ 40000
+#define KG_OI_BUFSZ         5
+#define KG_TABLE_ENTRY_SIZE 24              /* KGJ:995-999: i64 whichKmer, i32 otuIndex, i32 avgFromEnd, i32 functionIndex, f32 functionWt */
+
+/* The instance fields the hot path reads (KGJ:102-106), set by the CLI flags -a -O -m -M -g (KGJ:577-595). */
+typedef struct kg_params {
+    int32_t aa;                 /* -a : input is protein (1 container per sequence) instead of DNA (6)  */
+    int32_t order_constraint;   /* -O */
+    int32_t min_hits;           /* -m, reference default 5; must be >= 2                                */
+    int32_t min_weighted_hits;  /* -M, reference default 0                                              */
+    int32_t max_gap;            /* -g, reference default 200                                            */
+    uint32_t flags;             /* KG_F_*                                                               */
+} kg_params;
+
+#define KG_F_COUNTERS        1u  /* also count windows_valid / slots_inspected, slower     */
+#define KG_F_SKIP_AGGREGATE  2u  /* stop after the hit records (no CALL / OTU stage)                   */
+
+/* Binary records.  Text formatting (KGJ:398-404, 518-548) stays in host code. */
+typedef struct kg_hit {          /* replaces class Hit (KGJ:1213-1219) + its HitContainer id (KGJ:1262-1266) */
+    uint32_t container;          /* running container index: seq*6 + {+0,+1,+2,-0,-1,-2} (DNA) or seq (AA), KGJ:907-911 */
+    int32_t  from0InProt;
+    int32_t  oI;
+    int32_t  avgOffFromEnd;
+    int32_t  fI;
+    float    functionWt;
+} kg_hit;
+
+typedef struct kg_call {         /* one "CALL" line, KGJ:398-404 */
+    uint32_t container;
+    int32_t  start;              /* hits.get(0).from0InProt                 */
+    int32_t  end;                /* hits.get(lastHit).from0InProt + (K-1)   */
+    int32_t  count;              /* fICount                                 */
+    int32_t  fI;                 /* currentFI                               */
+    float    weightedHits;       /* float32, summed in list order           */
+} kg_call;
+
+typedef struct kg_otu {          /* the per-sequence oICounts buffer as printed by KGJ:516-524 */
+    int32_t n;
+    int32_t count[KG_OI_BUFSZ];
+    int32_t oI[KG_OI_BUFSZ];
+} kg_otu;
+
+typedef struct kg_stats {
+    int64_t n_seqs, n_containers, n_blocks;   /* blocks = wavefront work items ("contig window blocks") */
+    int64_t n_hits, n_calls;
+    int64_t residues;            /* translated positions (DNA: sum over 6 frames) or characters (AA)     */
+    int64_t windows;             /* 8-residue windows enumerated (KGJ:912 loop trips, all frames)        */
+    int64_t windows_valid;       /* windows that encode (KGJ:913-915); valid only with KG_F_COUNTERS     */
+    int64_t slots_inspected;     /* table entries inspected under KGJ:944-1034 semantics; KG_F_COUNTERS  */
+    int64_t table_bytes;         /* numSigs * 24                                                          */
+    float   ms_scan;             /* HIP-event time of the scan kernel (encode + probe + compaction)      */
+    float   ms_order;            /* prefix sums + ordered placement of the hit records                   */
+    float   ms_aggregate;        /* gatherHits / processSetOfHits kernels                                */
+    float   ms_total;            /* first kernel start -> last kernel end on the library's stream        */
+    int32_t scan_launches;       /* >1 when the hit staging buffer had to grow and the scan was re-run   */
+    int32_t reserved;
+} kg_stats;
+
+typedef struct kg_table  kg_table;
+typedef struct kg_result kg_result;
+
+/* ---- signature table: replaces readKmerTableHeader (KGJ:924-942) + the table stream of lookup (KGJ:944-1034) ---- */
+
+/* Read <path> = an uncompressed kmer.table.mem_map (KGJ:749), validate the header
+ * (3 x int64 LE: numSigs, entrySize, version) and make the table resident on HIP device <device>. */
+int kg_table_open(const char *path, int device, kg_table **out);
+/* Same from a file image in host memory (the host gunzips kmer.table.mem_map.gz, KGJ:750-753). */
+int kg_table_from_memory(const void *image, size_t nbytes, int device, kg_table **out);
+/* Adopt num_sigs 24-byte entries that already sit in device memory (not copied, not freed). */
+int kg_table_from_device(const void *d_entries, int64_t num_sigs, int device, kg_table **out);
+/* header fields (KmerMemoryInfo, KGJ:1194-1198) and the number of occupied slots */
+int kg_table_info(const kg_table *t, int64_t *num_sigs, int64_t *entry_size, int64_t *version, int64_t *occupied);
+void kg_table_close(kg_table *t);
+
+/* ---- the hot path: replaces prepareQuery/addKmers (KGJ:1051-1074, 900-922), the query sort
+ *      (KGJ:1076-1095), lookup (KGJ:944-1034) and gatherHits/processSetOfHits (KGJ:385-514) for a
+ *      batch of sequences.  seq = the raw concatenated sequence characters exactly as readFasta
+ *      hands them to prepareQuery (KGJ:780-783); offsets[n_seqs+1] in host memory. ---- */
+int kg_scan(kg_table *t, const kg_params *p, const uint8_t *seq, const int64_t *offsets,
+            int64_t n_seqs, kg_result **out);
+/* same with the sequence bytes already in device memory (offsets stay on the host) */
+int kg_scan_device(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64_t *offsets,
+                   int64_t n_seqs, kg_result **out);
+
+int kg_result_stats(const kg_result *r, kg_stats *out);
+/* Host views, copied from the device on first use; NULL on failure (see kg_last_error). */
+const kg_hit  *kg_result_hits(kg_result *r);                 /* n_hits, ordered by (container, from0InProt)   */
+const int64_t *kg_result_container_hit_start(kg_result *r);  /* n_containers + 1                              */
+const kg_call *kg_result_calls(kg_result *r);                /* n_calls, in the reference's emission order     */
+const int64_t *kg_result_container_call_start(kg_result *r); /* n_containers + 1                              */
+const kg_otu  *kg_result_otu(kg_result *r);                  /* n_seqs                                        */
+/* Device views (valid until kg_result_free) for callers that keep working in HBM. */
+const void    *kg_result_device_hits(const kg_result *r);
+const void    *kg_result_device_calls(const kg_result *r);
+void kg_result_free(kg_result *r);
+
+const char *kg_last_error(void);
+/* "libkmerguts_hip <version> gfx950" */
+const char *kg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

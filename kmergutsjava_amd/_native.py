@@ -1,0 +1,110 @@
+"""ctypes binding of libkmerguts_hip.so (C ABI: include/kmerguts_hip.h).
+
+The library is the product path.  If it is missing or cannot be loaded this module raises:
+there is no CPU fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkmerguts_hip.so")
+
+KG_OK = 0
+KG_F_COUNTERS = 1
+KG_F_SKIP_AGGREGATE = 2
+KG_OI_BUFSZ = 5
+
+# every symbol include/kmerguts_hip.h declares
+EXPORTS = (
+    "kg_table_open", "kg_table_from_memory", "kg_table_from_device", "kg_table_info", "kg_table_close",
+    "kg_scan", "kg_scan_device", "kg_result_stats", "kg_result_hits", "kg_result_container_hit_start",
+    "kg_result_calls", "kg_result_container_call_start", "kg_result_otu", "kg_result_device_hits",
+    "kg_result_device_calls", "kg_result_free", "kg_last_error", "kg_version",
+)
+
+HIT_DTYPE = np.dtype([("container", "<u4"), ("from0InProt", "<i4"), ("oI", "<i4"),
+                      ("avgOffFromEnd", "<i4"), ("fI", "<i4"), ("functionWt", "<f4")])
+CALL_DTYPE = np.dtype([("container", "<u4"), ("start", "<i4"), ("end", "<i4"), ("count", "<i4"),
+                       ("fI", "<i4"), ("weightedHits", "<f4")])
+OTU_DTYPE = np.dtype([("n", "<i4"), ("count", "<i4", (KG_OI_BUFSZ,)), ("oI", "<i4", (KG_OI_BUFSZ,))])
+assert HIT_DTYPE.itemsize == 24 and CALL_DTYPE.itemsize == 24 and OTU_DTYPE.itemsize == 44
+
+
+class KgParams(C.Structure):
+    _fields_ = [("aa", C.c_int32), ("order_constraint", C.c_int32), ("min_hits", C.c_int32),
+                ("min_weighted_hits", C.c_int32), ("max_gap", C.c_int32), ("flags", C.c_uint32)]
+
+
+class KgStats(C.Structure):
+    _fields_ = [("n_seqs", C.c_int64), ("n_containers", C.c_int64), ("n_blocks", C.c_int64),
+                ("n_hits", C.c_int64), ("n_calls", C.c_int64), ("residues", C.c_int64),
+                ("windows", C.c_int64), ("windows_valid", C.c_int64), ("slots_inspected", C.c_int64),
+                ("table_bytes", C.c_int64), ("ms_scan", C.c_float), ("ms_order", C.c_float),
+                ("ms_aggregate", C.c_float), ("ms_total", C.c_float), ("scan_launches", C.c_int32),
+                ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class KmerGutsNativeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libkmerguts_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise loudly when it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -m kmergutsjava_amd.build` "
+            "(hipcc --offload-arch=gfx950).  kmergutsjava_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
+    lib.kg_table_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.kg_table_from_memory.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.kg_table_from_device.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(vp)]
+    lib.kg_table_info.argtypes = [vp, i64p, i64p, i64p, i64p]
+    lib.kg_table_close.argtypes = [vp]
+    lib.kg_table_close.restype = None
+    lib.kg_scan.argtypes = [vp, C.POINTER(KgParams), vp, vp, C.c_int64, C.POINTER(vp)]
+    lib.kg_scan_device.argtypes = [vp, C.POINTER(KgParams), vp, vp, C.c_int64, C.POINTER(vp)]
+    lib.kg_result_stats.argtypes = [vp, C.POINTER(KgStats)]
+    for name in ("kg_result_hits", "kg_result_container_hit_start", "kg_result_calls",
+                 "kg_result_container_call_start", "kg_result_otu", "kg_result_device_hits",
+                 "kg_result_device_calls"):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = vp
+    lib.kg_result_free.argtypes = [vp]
+    lib.kg_result_free.restype = None
+    lib.kg_last_error.restype = C.c_char_p
+    lib.kg_version.restype = C.c_char_p
+    for name in EXPORTS:
+        getattr(lib, name)          # AttributeError if a declared symbol is not exported
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != KG_OK:
+        raise KmerGutsNativeError(rc, load().kg_last_error().decode("utf-8", "replace"))
+
+
+def view(ptr: int, count: int, dtype: np.dtype) -> np.ndarray:
+    """Copy `count` records at `ptr` (library-owned host memory) into a fresh numpy array."""
+    if count == 0:
+        return np.zeros(0, dtype=dtype)
+    if not ptr:
+        raise KmerGutsNativeError(-1, load().kg_last_error().decode("utf-8", "replace"))
+    buf = (C.c_uint8 * (count * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()

@@ -1,0 +1,46 @@
+"""Build the native pieces in-tree (hipcc cross-compiles gfx950 without a GPU).
+
+    python -m kmergutsjava_amd.build            # libkmerguts_hip.so
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libkmerguts_hip.so")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+               "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU fallback)")
+
+
+def _stale(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, "kmerguts_hip.hip"), os.path.join(CSRC, "kg_device.hpp"),
+            os.path.join(ROOT, "include", "kmerguts_hip.h")]
+    if force or _stale(LIB, srcs):
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-o", LIB, srcs[0]]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose=True))

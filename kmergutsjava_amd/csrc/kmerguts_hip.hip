@@ -1,0 +1,608 @@
+// kmerguts_hip.hip -- host side of libkmerguts_hip.so (C ABI in include/kmerguts_hip.h).
+//
+// Replaces, for a batch of sequences, the reference's run() body between readFasta and the
+// report printers (KGJ:776-816): prepareQuery/addKmers, the query sort, lookup and
+// gatherHits/processSetOfHits.  Everything runs on one HIP stream owned by the table object;
+// scratch and results come from the stream-ordered pool (hipMallocAsync) so that repeated
+// scans reuse the same HBM.
+#include "kg_device.hpp"
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(KG_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct kg_table {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_entries = false;
+    uint8_t *d_entries = nullptr;
+    uint8_t *d_tags = nullptr;
+    int64_t num_sigs = 0, entry_size = 0, version = 0;
+    uint64_t limit = 0;          // complete 24-byte records present
+    uint64_t magic = 0;
+    uint64_t occupied = 0;
+    double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
+    hipEvent_t ev[6] = {};
+};
+
+struct kg_result {
+    kg_table *tab = nullptr;
+    kg_stats st = {};
+    uint32_t per = 6;
+    // device
+    kg_hit *d_hits = nullptr;
+    int64_t *d_chs = nullptr;
+    kg_call *d_calls = nullptr;
+    int64_t *d_ccs = nullptr;
+    kg_otu *d_otu = nullptr;
+    // host copies (lazy)
+    std::vector<kg_hit> h_hits;
+    std::vector<int64_t> h_chs, h_ccs;
+    std::vector<kg_call> h_calls;
+    std::vector<kg_otu> h_otu;
+    bool have_hits = false, have_chs = false, have_calls = false, have_ccs = false, have_otu = false;
+};
+
+namespace {
+
+int dalloc(kg_table *t, void **p, size_t bytes)
+{
+    if (bytes == 0) bytes = 256;
+    HIP_TRY(hipMallocAsync(p, bytes, t->stream));
+    return KG_OK;
+}
+
+void dfree(kg_table *t, void *p)
+{
+    if (p) (void)hipFreeAsync(p, t->stream);
+}
+
+int table_finish(kg_table *t)
+{
+    // tag array + occupancy count: one streaming pass over the records
+    HIP_TRY(hipSetDevice(t->device));
+    unsigned __int128 one = 1;
+    if (t->num_sigs == 1) t->magic = ~0ull;
+    else t->magic = (uint64_t)((one << 64) / (unsigned __int128)(uint64_t)t->num_sigs);
+    uint64_t n_tags = t->limit + kg::kTagPad;
+    HIP_TRY(hipMalloc((void **)&t->d_tags, n_tags));
+    unsigned long long *d_occ = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_occ, 8));
+    HIP_TRY(hipMemsetAsync(d_occ, 0, 8, t->stream));
+    uint64_t want = (n_tags + 255) / 256;
+    uint32_t grid = (uint32_t)(want < 256ull * 16 ? (want ? want : 1) : 256ull * 16);
+    hipLaunchKernelGGL(kg::build_tags_kernel, dim3(grid), dim3(256), 0, t->stream, t->d_entries, t->limit, n_tags,
+                       t->d_tags, d_occ);
+    HIP_TRY(hipGetLastError());
+    unsigned long long occ = 0;
+    HIP_TRY(hipMemcpyAsync(&occ, d_occ, 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    HIP_TRY(hipFree(d_occ));
+    t->occupied = occ;
+    for (auto &e : t->ev) HIP_TRY(hipEventCreate(&e));
+    return KG_OK;
+}
+
+int table_new(int device, kg_table **out)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(KG_ERR_DEVICE, "no HIP device: libkmerguts_hip needs an MI355X (gfx950) GPU; there is no CPU path");
+    if (device < 0 || device >= ndev) return fail(KG_ERR_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    kg_table *t = new (std::nothrow) kg_table();
+    if (!t) return fail(KG_ERR_NOMEM, "out of host memory");
+    t->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete t; return fail(KG_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    // keep freed scratch in the pool: the next scan reuses it without going back to the driver
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+        uint64_t thr = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    *out = t;
+    return KG_OK;
+}
+
+int64_t rd_i64le(const uint8_t *b)
+{
+    uint64_t v = 0;
+    for (int i = 7; i >= 0; i--) v = (v << 8) | b[i];
+    return (int64_t)v;
+}
+
+int parse_header(const uint8_t *hdr, kg_table *t)
+{
+    // readKmerTableHeader, KGJ:933-935
+    t->num_sigs = rd_i64le(hdr);
+    t->entry_size = rd_i64le(hdr + 8);
+    t->version = rd_i64le(hdr + 16);      // never checked by the reference (KGJ:97 VERSION unused)
+    if (t->num_sigs <= 0) return fail(KG_ERR_FORMAT, "kmer table header: numSigs <= 0");
+    if (t->entry_size != KG_TABLE_ENTRY_SIZE)
+        return fail(KG_ERR_FORMAT, "kmer table header: entrySize != 24 (the reference reads 24-byte records, KGJ:995-999)");
+    return KG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *kg_last_error(void) { return g_err.c_str(); }
+const char *kg_version(void) { return "libkmerguts_hip 0.1.0 gfx950"; }
+
+int kg_table_from_memory(const void *image, size_t nbytes, int device, kg_table **out)
+{
+    if (!image || !out) return fail(KG_ERR_ARG, "null argument");
+    if (nbytes < 24) return fail(KG_ERR_FORMAT, "kmer table image shorter than its 24-byte header");
+    kg_table *t = nullptr;
+    int rc = table_new(device, &t);
+    if (rc) return rc;
+    rc = parse_header((const uint8_t *)image, t);
+    if (rc) { kg_table_close(t); return rc; }
+    t->limit = (nbytes - 24) / KG_TABLE_ENTRY_SIZE;       // a trailing partial record is an EOF for the reference
+    size_t bytes = (size_t)t->limit * KG_TABLE_ENTRY_SIZE;
+    t->own_entries = true;
+    hipError_t e = hipMalloc((void **)&t->d_entries, bytes ? bytes : 256);
+    if (e != hipSuccess) { kg_table_close(t); return fail(KG_ERR_NOMEM, std::string("hipMalloc(table): ") + hipGetErrorString(e)); }
+    if (bytes) {
+        e = hipMemcpy(t->d_entries, (const uint8_t *)image + 24, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { kg_table_close(t); return fail(KG_ERR_DEVICE, std::string("hipMemcpy(table): ") + hipGetErrorString(e)); }
+    }
+    rc = table_finish(t);
+    if (rc) { kg_table_close(t); return rc; }
+    *out = t;
+    return KG_OK;
+}
+
+int kg_table_open(const char *path, int device, kg_table **out)
+{
+    if (!path || !out) return fail(KG_ERR_ARG, "null argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(KG_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
+    uint8_t hdr[24];
+    if (fread(hdr, 1, 24, f) != 24) { fclose(f); return fail(KG_ERR_FORMAT, "kmer table file shorter than its 24-byte header"); }
+    if (fseeko(f, 0, SEEK_END) != 0) { fclose(f); return fail(KG_ERR_IO, "fseek failed"); }
+    off_t fsz = ftello(f);
+    if (fseeko(f, 24, SEEK_SET) != 0) { fclose(f); return fail(KG_ERR_IO, "fseek failed"); }
+    kg_table *t = nullptr;
+    int rc = table_new(device, &t);
+    if (rc) { fclose(f); return rc; }
+    rc = parse_header(hdr, t);
+    if (rc) { fclose(f); kg_table_close(t); return rc; }
+    t->limit = (uint64_t)(fsz - 24) / KG_TABLE_ENTRY_SIZE;
+    size_t bytes = (size_t)t->limit * KG_TABLE_ENTRY_SIZE;
+    t->own_entries = true;
+    hipError_t e = hipMalloc((void **)&t->d_entries, bytes ? bytes : 256);
+    if (e != hipSuccess) { fclose(f); kg_table_close(t); return fail(KG_ERR_NOMEM, std::string("hipMalloc(table): ") + hipGetErrorString(e)); }
+    // stream the file through two pinned 64 MiB buffers
+    const size_t CH = 64u << 20;
+    uint8_t *pin[2] = {nullptr, nullptr};
+    hipEvent_t done[2];
+    bool ok = hipHostMalloc((void **)&pin[0], CH) == hipSuccess && hipHostMalloc((void **)&pin[1], CH) == hipSuccess &&
+              hipEventCreate(&done[0]) == hipSuccess && hipEventCreate(&done[1]) == hipSuccess;
+    size_t at = 0;
+    int which = 0;
+    bool used[2] = {false, false};
+    while (ok && at < bytes) {
+        size_t n = bytes - at < CH ? bytes - at : CH;
+        if (used[which]) ok = hipEventSynchronize(done[which]) == hipSuccess;
+        if (!ok) break;
+        if (fread(pin[which], 1, n, f) != n) { ok = false; g_err = "short read on kmer table file"; break; }
+        ok = hipMemcpyAsync(t->d_entries + at, pin[which], n, hipMemcpyHostToDevice, t->stream) == hipSuccess &&
+             hipEventRecord(done[which], t->stream) == hipSuccess;
+        used[which] = true;
+        at += n;
+        which ^= 1;
+    }
+    if (ok) ok = hipStreamSynchronize(t->stream) == hipSuccess;
+    fclose(f);
+    if (pin[0]) (void)hipHostFree(pin[0]);
+    if (pin[1]) (void)hipHostFree(pin[1]);
+    (void)hipEventDestroy(done[0]);
+    (void)hipEventDestroy(done[1]);
+    if (!ok) { kg_table_close(t); return fail(KG_ERR_IO, "reading/uploading the kmer table failed" + (g_err.empty() ? std::string() : ": " + g_err)); }
+    rc = table_finish(t);
+    if (rc) { kg_table_close(t); return rc; }
+    *out = t;
+    return KG_OK;
+}
+
+int kg_table_from_device(const void *d_entries, int64_t num_sigs, int device, kg_table **out)
+{
+    if (!d_entries || !out) return fail(KG_ERR_ARG, "null argument");
+    if (num_sigs <= 0) return fail(KG_ERR_ARG, "num_sigs <= 0");
+    kg_table *t = nullptr;
+    int rc = table_new(device, &t);
+    if (rc) return rc;
+    t->num_sigs = num_sigs;
+    t->entry_size = KG_TABLE_ENTRY_SIZE;
+    t->version = 1;
+    t->limit = (uint64_t)num_sigs;
+    t->own_entries = false;
+    t->d_entries = (uint8_t *)d_entries;
+    rc = table_finish(t);
+    if (rc) { kg_table_close(t); return rc; }
+    *out = t;
+    return KG_OK;
+}
+
+int kg_table_info(const kg_table *t, int64_t *num_sigs, int64_t *entry_size, int64_t *version, int64_t *occupied)
+{
+    if (!t) return fail(KG_ERR_ARG, "null table");
+    if (num_sigs) *num_sigs = t->num_sigs;
+    if (entry_size) *entry_size = t->entry_size;
+    if (version) *version = t->version;
+    if (occupied) *occupied = (int64_t)t->occupied;
+    return KG_OK;
+}
+
+void kg_table_close(kg_table *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    if (t->own_entries && t->d_entries) (void)hipFree(t->d_entries);
+    if (t->d_tags) (void)hipFree(t->d_tags);
+    for (auto &e : t->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+}
+
+void kg_result_free(kg_result *r)
+{
+    if (!r) return;
+    kg_table *t = r->tab;
+    if (t) {
+        (void)hipSetDevice(t->device);
+        dfree(t, r->d_hits); dfree(t, r->d_chs); dfree(t, r->d_calls); dfree(t, r->d_ccs); dfree(t, r->d_otu);
+    }
+    delete r;
+}
+
+}  // extern "C"
+
+namespace {
+
+// exclusive prefix sum of d_in[n] -> d_out[n], total -> d_total (device uint64)
+int prefix_sum(kg_table *t, const uint32_t *d_in, uint64_t n, uint32_t *d_out, uint64_t *d_partial, uint64_t *d_total)
+{
+    uint32_t nb = (uint32_t)((n + kg::kScanChunk - 1) / kg::kScanChunk);
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(kg::scan_partials_kernel, dim3(nb), dim3(kg::kScanThreads), 0, t->stream, d_in, n, d_partial);
+    hipLaunchKernelGGL(kg::scan_top_kernel, dim3(1), dim3(kg::kScanThreads), 0, t->stream, d_partial, nb, d_total);
+    hipLaunchKernelGGL(kg::scan_final_kernel, dim3(nb), dim3(kg::kScanThreads), 0, t->stream, d_in, n, d_partial, d_out);
+    HIP_TRY(hipGetLastError());
+    return KG_OK;
+}
+
+struct Scratch {
+    kg_table *t;
+    std::vector<void *> ptrs;
+    explicit Scratch(kg_table *tt) : t(tt) {}
+    ~Scratch() { for (void *p : ptrs) dfree(t, p); }
+    template <typename T> int get(T **p, size_t count)
+    {
+        void *v = nullptr;
+        int rc = dalloc(t, &v, count * sizeof(T));
+        if (rc) return rc;
+        ptrs.push_back(v);
+        *p = (T *)v;
+        return KG_OK;
+    }
+};
+
+template <bool AA>
+int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64_t *offsets, int64_t n_seqs, kg_result *res)
+{
+    constexpr uint32_t PER = AA ? 1 : 6;
+    const bool counters = (p->flags & KG_F_COUNTERS) != 0;
+    kg_stats &st = res->st;
+    res->per = PER;
+
+    // ---- host: window blocks per sequence (KGJ:912 trip counts) ----
+    std::vector<uint32_t> ibase((size_t)n_seqs + 1);
+    uint64_t nblocks = 0, windows = 0, residues = 0;
+    for (int64_t k = 0; k < n_seqs; k++) {
+        int64_t L = offsets[k + 1] - offsets[k];
+        if (L < 0) return fail(KG_ERR_ARG, "offsets must be non-decreasing");
+        if (L > 0xFFFFFFF0ll) return fail(KG_ERR_LIMIT, "a single sequence longer than 2^32-16 characters");
+        ibase[(size_t)k] = (uint32_t)nblocks;
+        uint64_t nb;
+        if (AA) {
+            uint64_t nwin = L >= 9 ? (uint64_t)L - 8 : 0;       // i < len - 8
+            windows += nwin;
+            residues += (uint64_t)L;
+            nb = (nwin + kg::kAaWinPerBlock - 1) / kg::kAaWinPerBlock;
+        } else {
+            uint64_t npos = L >= 24 ? (uint64_t)L - 23 : 0;     // forward positions that start a 24-base window
+            windows += 2 * npos;
+            for (int f = 0; f < 3; f++)
+                if (L - f >= 3) residues += 2 * (uint64_t)((L - f) / 3);
+            nb = (npos + kg::kDnaPosPerBlock - 1) / kg::kDnaPosPerBlock;
+        }
+        nblocks += nb;
+        if (nblocks > 0x7FFFFFFFull / PER) return fail(KG_ERR_LIMIT, "batch too large: more than 2^31-1 window rows; split the batch");
+    }
+    ibase[(size_t)n_seqs] = (uint32_t)nblocks;
+    if (windows > 0xFFFFFFFFull) return fail(KG_ERR_LIMIT, "batch too large: more than 2^32-1 windows; split the batch");
+    const uint64_t n_rows = nblocks * PER;
+    const uint64_t n_cont = (uint64_t)n_seqs * PER;
+    st.n_seqs = n_seqs; st.n_containers = (int64_t)n_cont; st.n_blocks = (int64_t)nblocks;
+    st.residues = (int64_t)residues; st.windows = (int64_t)windows;
+    st.table_bytes = t->num_sigs * (int64_t)KG_TABLE_ENTRY_SIZE;
+
+    Scratch sc(t);
+    int rc;
+    int64_t *d_off = nullptr; uint32_t *d_ibase = nullptr;
+    if ((rc = sc.get(&d_off, (size_t)n_seqs + 1))) return rc;
+    if ((rc = sc.get(&d_ibase, (size_t)n_seqs + 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_off, offsets, ((size_t)n_seqs + 1) * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(d_ibase, ibase.data(), ((size_t)n_seqs + 1) * 4, hipMemcpyHostToDevice, t->stream));
+
+    kg::BlockDesc *d_blocks = nullptr;
+    uint32_t *d_counts = nullptr, *d_offs = nullptr, *d_bsb = nullptr;
+    uint64_t *d_partial = nullptr, *d_totals = nullptr;   // totals[0] hits, [1] cursor, [2] ctr_valid, [3] ctr_slots, [4] calls
+    if ((rc = sc.get(&d_blocks, nblocks))) return rc;
+    if ((rc = sc.get(&d_counts, n_rows))) return rc;
+    if ((rc = sc.get(&d_offs, n_rows))) return rc;
+    if ((rc = sc.get(&d_bsb, nblocks))) return rc;
+    uint64_t max_scan = n_rows > n_cont ? n_rows : n_cont;
+    if ((rc = sc.get(&d_partial, (size_t)(max_scan / kg::kScanChunk + 2)))) return rc;
+    if ((rc = sc.get(&d_totals, 8))) return rc;
+    HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
+
+    if ((rc = dalloc(t, (void **)&res->d_chs, (n_cont + 1) * 8))) return rc;
+
+    HIP_TRY(hipEventRecord(t->ev[0], t->stream));
+    if (nblocks) {
+        hipLaunchKernelGGL(kg::build_blocks_kernel, dim3((uint32_t)((nblocks + 255) / 256)), dim3(256), 0, t->stream,
+                           d_off, d_ibase, (uint32_t)n_seqs, (uint32_t)nblocks, d_blocks);
+        HIP_TRY(hipGetLastError());
+    }
+
+    // ---- scan: encode + probe + staged compaction; re-run once if the staging area was too small ----
+    uint64_t stage_cap = (uint64_t)((double)windows * t->stage_ratio) + 4096;
+    if (stage_cap > windows) stage_cap = windows;
+    if (stage_cap == 0) stage_cap = 1;
+    kg_hit *d_stage = nullptr;
+    uint64_t n_hits = 0;
+    st.scan_launches = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = dalloc(t, (void **)&d_stage, stage_cap * sizeof(kg_hit)))) return rc;
+        kg::ScanArgs a;
+        a.tab.entries = t->d_entries; a.tab.tags = t->d_tags; a.tab.limit = t->limit;
+        a.tab.num_sigs = (uint64_t)t->num_sigs; a.tab.magic = t->magic;
+        a.seq = d_seq; a.blocks = d_blocks; a.n_blocks = (uint32_t)nblocks;
+        a.counts = d_counts; a.block_stage_base = d_bsb; a.stage = d_stage;
+        a.cursor = (unsigned long long *)(d_totals + 1); a.stage_cap = stage_cap;
+        a.ctr = (unsigned long long *)(d_totals + 2);
+        HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
+        HIP_TRY(hipEventRecord(t->ev[1], t->stream));
+        if (nblocks) {
+            uint64_t wgs = (nblocks + kg::kWavesPerWG - 1) / kg::kWavesPerWG;
+            uint32_t grid = (uint32_t)(wgs < 256ull * 64 ? wgs : 256ull * 64);   // persistent waves stride over the blocks
+            if (counters)
+                hipLaunchKernelGGL((kg::scan_kernel<AA, true>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, t->stream, a);
+            else
+                hipLaunchKernelGGL((kg::scan_kernel<AA, false>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, t->stream, a);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(t->ev[2], t->stream));
+        st.scan_launches++;
+        if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) { dfree(t, d_stage); return rc; }
+        uint64_t h_tot[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 32, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        n_hits = n_rows ? h_tot[0] : 0;
+        st.windows_valid = counters ? (int64_t)h_tot[2] : -1;
+        st.slots_inspected = counters ? (int64_t)h_tot[3] : -1;
+        if (h_tot[1] <= stage_cap) break;
+        // staging overflow: now the exact need is known
+        dfree(t, d_stage); d_stage = nullptr;
+        if (attempt == 1) return fail(KG_ERR_DEVICE, "staging overflow after resize (internal error)");
+        stage_cap = h_tot[1];
+    }
+    if (windows) {
+        double ratio = (double)n_hits / (double)windows * 1.25 + 1e-3;
+        if (ratio > t->stage_ratio) t->stage_ratio = ratio > 1.0 ? 1.0 : ratio;
+    }
+    st.n_hits = (int64_t)n_hits;
+
+    // ---- ordered placement ----
+    if ((rc = dalloc(t, (void **)&res->d_hits, n_hits * sizeof(kg_hit)))) { dfree(t, d_stage); return rc; }
+    if (nblocks) {
+        uint32_t grid = (uint32_t)((nblocks + kg::kWavesPerWG - 1) / kg::kWavesPerWG);
+        hipLaunchKernelGGL((kg::place_kernel<AA>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, t->stream, d_blocks,
+                           (uint32_t)nblocks, d_counts, d_offs, d_bsb, d_stage, res->d_hits);
+    }
+    hipLaunchKernelGGL((kg::container_starts_kernel<AA>), dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream,
+                       d_ibase, (uint32_t)n_seqs, d_offs, n_rows, d_totals, res->d_chs);
+    HIP_TRY(hipGetLastError());
+    dfree(t, d_stage);
+    HIP_TRY(hipEventRecord(t->ev[3], t->stream));
+
+    // ---- aggregation: CALL records and OTU votes ----
+    uint64_t n_calls = 0;
+    if (!(p->flags & KG_F_SKIP_AGGREGATE)) {
+        kg::AggParams ap;
+        ap.min_hits = p->min_hits; ap.min_weighted_hits = p->min_weighted_hits;
+        ap.max_gap = p->max_gap; ap.order_constraint = p->order_constraint ? 1 : 0;
+        uint8_t *d_acc = nullptr; uint32_t *d_ccnt = nullptr, *d_coff = nullptr; kg::CallSpan *d_spans = nullptr;
+        if ((rc = sc.get(&d_acc, n_hits))) return rc;
+        if ((rc = sc.get(&d_ccnt, n_cont))) return rc;
+        if ((rc = sc.get(&d_coff, n_cont))) return rc;
+        if ((rc = dalloc(t, (void **)&res->d_ccs, (n_cont + 1) * 8))) return rc;
+        if ((rc = dalloc(t, (void **)&res->d_otu, (size_t)(n_seqs ? n_seqs : 1) * sizeof(kg_otu)))) return rc;
+        uint32_t cgrid = (uint32_t)((n_cont + 63) / 64);
+        if (n_cont) {
+            hipLaunchKernelGGL((kg::calls_kernel<false>), dim3(cgrid), dim3(64), 0, t->stream, res->d_hits, res->d_chs, n_cont,
+                               ap, d_acc, d_ccnt, (const uint32_t *)nullptr, (kg_call *)nullptr, (kg::CallSpan *)nullptr);
+            HIP_TRY(hipGetLastError());
+        }
+        if ((rc = prefix_sum(t, d_ccnt, n_cont, d_coff, d_partial, d_totals + 4))) return rc;
+        uint64_t h_calls = 0;
+        HIP_TRY(hipMemcpyAsync(&h_calls, d_totals + 4, 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        n_calls = n_cont ? h_calls : 0;
+        if ((rc = dalloc(t, (void **)&res->d_calls, n_calls * sizeof(kg_call)))) return rc;
+        if ((rc = sc.get(&d_spans, n_calls))) return rc;
+        if (n_cont) {
+            hipLaunchKernelGGL((kg::calls_kernel<true>), dim3(cgrid), dim3(64), 0, t->stream, res->d_hits, res->d_chs, n_cont,
+                               ap, d_acc, (uint32_t *)nullptr, d_coff, res->d_calls, d_spans);
+        }
+        hipLaunchKernelGGL(kg::call_starts_kernel, dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream, d_coff,
+                           n_cont, d_totals + 4, res->d_ccs);
+        if (n_seqs) {
+            hipLaunchKernelGGL(kg::otu_kernel, dim3((uint32_t)((n_seqs + 63) / 64)), dim3(64), 0, t->stream, res->d_hits, d_acc,
+                               res->d_calls, d_spans, res->d_ccs, (uint32_t)n_seqs, PER, res->d_otu);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    st.n_calls = (int64_t)n_calls;
+    HIP_TRY(hipEventRecord(t->ev[4], t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, t->ev[1], t->ev[2])); st.ms_scan = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, t->ev[2], t->ev[3])); st.ms_order = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, t->ev[3], t->ev[4])); st.ms_aggregate = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, t->ev[0], t->ev[4])); st.ms_total = ms;
+    return KG_OK;
+}
+
+int scan_entry(kg_table *t, const kg_params *p, const uint8_t *seq, bool on_device, const int64_t *offsets, int64_t n_seqs,
+               kg_result **out)
+{
+    if (!t || !p || !offsets || !out || n_seqs < 0) return fail(KG_ERR_ARG, "null or negative argument");
+    if (n_seqs > 0x7FFFFFF0ll / 6) return fail(KG_ERR_LIMIT, "too many sequences in one batch");
+    if (p->min_hits < 2)
+        return fail(KG_ERR_UNSUPPORTED, "minHits < 2: the reference throws in processSetOfHits (KGJ:442); refusing");
+    HIP_TRY(hipSetDevice(t->device));
+    int64_t total = offsets[n_seqs] - offsets[0];
+    if (total < 0) return fail(KG_ERR_ARG, "offsets must be non-decreasing");
+    if (!seq && total > 0) return fail(KG_ERR_ARG, "null sequence buffer");
+    kg_result *r = new (std::nothrow) kg_result();
+    if (!r) return fail(KG_ERR_NOMEM, "out of host memory");
+    r->tab = t;
+    uint8_t *d_seq = nullptr;
+    int rc = KG_OK;
+    if (!on_device) {
+        size_t end = (size_t)offsets[n_seqs];
+        rc = dalloc(t, (void **)&d_seq, end + 16);
+        if (rc == KG_OK && end) {
+            hipError_t e = hipMemcpyAsync(d_seq, seq, end, hipMemcpyHostToDevice, t->stream);
+            if (e != hipSuccess) rc = fail(KG_ERR_DEVICE, std::string("hipMemcpyAsync(seq): ") + hipGetErrorString(e));
+        }
+    }
+    if (rc == KG_OK) {
+        const uint8_t *s = on_device ? seq : d_seq;
+        rc = p->aa ? scan_impl<true>(t, p, s, offsets, n_seqs, r) : scan_impl<false>(t, p, s, offsets, n_seqs, r);
+    }
+    if (d_seq) dfree(t, d_seq);
+    if (rc != KG_OK) {
+        std::string keep = g_err;
+        (void)hipStreamSynchronize(t->stream);
+        kg_result_free(r);
+        g_err = keep;
+        return rc;
+    }
+    *out = r;
+    return KG_OK;
+}
+
+template <typename T>
+const T *host_view(kg_result *r, std::vector<T> &v, bool &have, const T *d, size_t n)
+{
+    if (have) return v.data();
+    if (!d && n) { g_err = "record kind not computed (KG_F_SKIP_AGGREGATE?)"; return nullptr; }
+    v.resize(n ? n : 1);
+    if (n) {
+        if (hipSetDevice(r->tab->device) != hipSuccess ||
+            hipMemcpy(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) {
+            g_err = "device to host copy failed";
+            return nullptr;
+        }
+    }
+    have = true;
+    return v.data();
+}
+
+}  // namespace
+
+extern "C" {
+
+int kg_scan(kg_table *t, const kg_params *p, const uint8_t *seq, const int64_t *offsets, int64_t n_seqs, kg_result **out)
+{
+    return scan_entry(t, p, seq, false, offsets, n_seqs, out);
+}
+
+int kg_scan_device(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64_t *offsets, int64_t n_seqs,
+                   kg_result **out)
+{
+    return scan_entry(t, p, d_seq, true, offsets, n_seqs, out);
+}
+
+int kg_result_stats(const kg_result *r, kg_stats *out)
+{
+    if (!r || !out) return fail(KG_ERR_ARG, "null argument");
+    *out = r->st;
+    return KG_OK;
+}
+
+const kg_hit *kg_result_hits(kg_result *r)
+{
+    return r ? host_view(r, r->h_hits, r->have_hits, r->d_hits, (size_t)r->st.n_hits) : nullptr;
+}
+const int64_t *kg_result_container_hit_start(kg_result *r)
+{
+    return r ? host_view(r, r->h_chs, r->have_chs, r->d_chs, (size_t)r->st.n_containers + 1) : nullptr;
+}
+const kg_call *kg_result_calls(kg_result *r)
+{
+    return r ? host_view(r, r->h_calls, r->have_calls, r->d_calls, (size_t)r->st.n_calls) : nullptr;
+}
+const int64_t *kg_result_container_call_start(kg_result *r)
+{
+    if (!r) return nullptr;
+    if (!r->d_ccs) { g_err = "calls not computed (KG_F_SKIP_AGGREGATE)"; return nullptr; }
+    return host_view(r, r->h_ccs, r->have_ccs, r->d_ccs, (size_t)r->st.n_containers + 1);
+}
+const kg_otu *kg_result_otu(kg_result *r)
+{
+    if (!r) return nullptr;
+    if (!r->d_otu) { g_err = "OTU votes not computed (KG_F_SKIP_AGGREGATE)"; return nullptr; }
+    return host_view(r, r->h_otu, r->have_otu, r->d_otu, (size_t)r->st.n_seqs);
+}
+const void *kg_result_device_hits(const kg_result *r) { return r ? r->d_hits : nullptr; }
+const void *kg_result_device_calls(const kg_result *r) { return r ? r->d_calls : nullptr; }
+
+}  // extern "C"

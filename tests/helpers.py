@@ -1,0 +1,45 @@
+"""Shared helpers of the parity tests."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def assert_same_records(gpu, ora, what=""):
+    """gpu: kmergutsjava_amd.hotpath.ScanResult, ora: dict from oracle.kgo.run.  Bit-exact."""
+    gh, oh = gpu.hits(), ora["hits"]
+    assert gpu.stats["n_hits"] == len(oh), "%s n_hits %d != %d" % (what, gpu.stats["n_hits"], len(oh))
+    assert gh.tobytes() == oh.tobytes(), "%s hit records differ (first diff at %s)" % (what, _first_diff(gh, oh))
+    assert np.array_equal(gpu.container_hit_start(), ora["container_hit_start"]), what + " container_hit_start"
+    gc, oc = gpu.calls(), ora["calls"]
+    assert len(gc) == len(oc), "%s n_calls %d != %d" % (what, len(gc), len(oc))
+    assert gc.tobytes() == oc.tobytes(), "%s call records differ (first diff at %s)" % (what, _first_diff(gc, oc))
+    assert np.array_equal(gpu.container_call_start(), ora["container_call_start"]), what + " container_call_start"
+    go, oo = gpu.otu(), ora["otu"]
+    assert go.tobytes() == oo.tobytes(), "%s OTU records differ (first diff at %s)" % (what, _first_diff(go, oo))
+    assert gpu.stats["residues"] == ora["residues"], what + " residues"
+
+
+def _first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i].tobytes() != b[i].tobytes():
+            return "%d: %s vs %s" % (i, a[i], b[i])
+    return "length %d vs %d" % (len(a), len(b))
+
+
+def plant(seq_bytes: bytes, off, keys, every=40, dna=True, start=10):
+    """Overwrite stretches of the sequences with decoded signature k-mers so that hits occur."""
+    from kmergutsjava_amd import synth
+    s = bytearray(seq_bytes)
+    ki = 0
+    for k in range(len(off) - 1):
+        a, b = int(off[k]), int(off[k + 1])
+        p = a + start
+        span = 24 if dna else 8
+        while p + span <= b and ki < len(keys):
+            pep = synth.decode_kmer(int(keys[ki]))
+            word = synth.back_translate(pep) if dna else pep
+            s[p:p + span] = word.encode()
+            ki += 1
+            p += every
+    return bytes(s)

@@ -1,0 +1,182 @@
+"""GPU parity: libkmerguts_hip (through the C ABI) against the CPU oracle, bit-exact.
+
+PARITY STATUS of the oracle itself: unpinned (the reference has no golden vectors for this path
+and cannot run here; see oracle/kg_oracle.h).  These tests pin HIP == oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_same_records, plant
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    from kmergutsjava_amd import hotpath
+    return hotpath
+
+
+def _img(rec):
+    from kmergutsjava_amd import synth
+    return synth.table_image(rec)
+
+
+def test_dna_planted_hits(hp, oracle):
+    from kmergutsjava_amd import synth
+    rec, placed, keys = synth.random_table(50021, 0.6, 7)
+    img = _img(rec)
+    seq, off = synth.dna_uniform_config(7, 1900, 11)
+    sb = plant(seq.numpy().tobytes(), off, keys.tolist(), every=37)
+    with hp.SignatureTable.from_bytes(img) as tab:
+        assert tab.info()["numSigs"] == 50021 and tab.info()["occupied"] == placed
+        for mh in (2, 5):
+            ora = oracle.run(img, sb, off, lookup_mode=1, min_hits=mh)
+            with tab.scan(sb, off, hp.Params(min_hits=mh, counters=True)) as r:
+                assert_same_records(r, ora, "dna planted mh=%d" % mh)
+                assert r.stats["windows_valid"] == ora["windows_valid"]
+                assert r.stats["slots_inspected"] == ora["slots_inspected"]
+            assert len(ora["hits"]) > 100
+
+
+def test_literal_lookup_equals_hip(hp, oracle):
+    """HIP direct probing == the reference's sorted merge-join (oracle lookup_mode 0)."""
+    from kmergutsjava_amd import synth
+    rec, placed, keys = synth.random_table(20011, 0.9, 17)      # long probe clusters
+    img = _img(rec)
+    seq, off = synth.dna_uniform_config(5, 3000, 12)
+    sb = plant(seq.numpy().tobytes(), off, keys.tolist(), every=29)
+    ora = oracle.run(img, sb, off, lookup_mode=0, min_hits=3)
+    with hp.SignatureTable.from_bytes(img) as tab, tab.scan(sb, off, hp.Params(min_hits=3)) as r:
+        assert_same_records(r, ora, "literal merge-join")
+
+
+@pytest.mark.parametrize("dna", [True, False])
+@pytest.mark.parametrize("oc", [False, True])
+def test_high_density_calls_and_otu(hp, oracle, dna, oc):
+    from kmergutsjava_amd import synth
+    seq, off, rec, keys = synth.high_density_config(24, 220, 40009, 9000, dna=dna)
+    img = _img(rec)
+    sb = seq.numpy().tobytes()
+    for mh, gap in ((5, 200), (2, 8), (3, 30), (2, 7)):
+        ora = oracle.run(img, sb, off, aa=not dna, lookup_mode=1, min_hits=mh, max_gap=gap, order_constraint=oc)
+        with hp.SignatureTable.from_bytes(img) as tab:
+            with tab.scan(sb, off, hp.Params(aa=not dna, min_hits=mh, max_gap=gap, order_constraint=oc)) as r:
+                assert_same_records(r, ora, "high density dna=%s oc=%s mh=%d gap=%d" % (dna, oc, mh, gap))
+        if mh == 5 and not oc:
+            assert len(ora["calls"]) > 50 and ora["otu"]["n"].max() >= 3
+
+
+def test_aa_plumbing_slice(hp, oracle):
+    from kmergutsjava_amd import synth
+    seq, off, rec, placed = synth.plumbing_config(n_seqs=600, num_sigs=100003, n_sigs=50000)
+    img = _img(rec)
+    sb = seq.numpy().tobytes()
+    ora = oracle.run(img, sb, off, aa=True, lookup_mode=1)
+    with hp.SignatureTable.from_bytes(img) as tab, tab.scan(sb, off, hp.Params(aa=True, counters=True)) as r:
+        assert_same_records(r, ora, "aa plumbing")
+        assert r.stats["windows_valid"] == ora["windows_valid"]
+        assert r.stats["slots_inspected"] == ora["slots_inspected"]
+    assert len(ora["hits"]) > 1000
+
+
+def test_ragged_short_and_dirty_inputs(hp, oracle):
+    """Empty batch, zero-length and sub-window sequences, lowercase / IUPAC / junk characters."""
+    from kmergutsjava_amd import synth
+    rec, placed, keys = synth.random_table(30011, 0.5, 3)
+    img = _img(rec)
+    rng = np.random.default_rng(5)
+    with hp.SignatureTable.from_bytes(img) as tab:
+        # empty batch
+        for aa in (False, True):
+            ora = oracle.run(img, b"", np.zeros(1, np.int64), aa=aa, lookup_mode=1)
+            with tab.scan(b"", np.zeros(1, np.int64), hp.Params(aa=aa)) as r:
+                assert_same_records(r, ora, "empty batch")
+        # DNA: every length 0..80 plus block-boundary lengths, with dirt
+        lens = list(range(0, 81)) + [191, 192, 193, 214, 215, 216, 217, 383, 384, 385, 407, 408, 600]
+        alphabet = np.frombuffer(b"ACGTacgtuUNnRYxX*-", dtype=np.uint8)
+        parts = []
+        for L in lens:
+            s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L)
+            dirty = rng.random(L) < 0.04
+            s[dirty] = rng.choice(alphabet, size=int(dirty.sum()))
+            parts.append(s)
+        off = synth.offsets_of(np.asarray(lens))
+        sb = plant(np.concatenate(parts).tobytes(), off, keys.tolist(), every=31, start=0)
+        ora = oracle.run(img, sb, off, lookup_mode=1, min_hits=2)
+        with tab.scan(sb, off, hp.Params(min_hits=2, counters=True)) as r:
+            assert_same_records(r, ora, "ragged dna")
+            assert r.stats["windows_valid"] == ora["windows_valid"]
+        # protein: lengths 0..40 + block boundaries, lowercase and X/U/* are invalid residues
+        lens = list(range(0, 41)) + [63, 64, 65, 71, 72, 73, 127, 128, 129, 136, 137, 300]
+        alphabet = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYacdxXU*BZ", dtype=np.uint8)
+        parts = [rng.choice(alphabet, size=L, p=None) for L in lens]
+        off = synth.offsets_of(np.asarray(lens))
+        sb = plant(np.concatenate(parts).tobytes(), off, keys.tolist(), every=11, dna=False, start=0)
+        ora = oracle.run(img, sb, off, aa=True, lookup_mode=1, min_hits=2)
+        with tab.scan(sb, off, hp.Params(aa=True, min_hits=2, counters=True)) as r:
+            assert_same_records(r, ora, "ragged aa")
+            assert r.stats["windows_valid"] == ora["windows_valid"]
+        assert len(ora["hits"]) > 20
+
+
+def test_table_edges(hp, oracle):
+    """No wrap-around at the end of the table, truncated file, file longer than numSigs,
+    negative keys (occupied, never matching), fingerprint-sharing keys in one cluster."""
+    from kmergutsjava_amd import synth
+    import struct
+    n = 4099
+    rec, placed, keys = synth.random_table(n, 0.97, 23)          # nearly full: clusters reach the end
+    img = _img(rec)
+    seq, off = synth.dna_uniform_config(4, 2500, 13)
+    allk = keys.tolist()
+    sb = plant(seq.numpy().tobytes(), off, allk, every=25)
+    variants = {
+        "full": img,
+        "truncated": img[:24 + 24 * 3000 + 7],                       # partial trailing record = EOF
+        "longer": img + img[24:24 + 24 * 50],                         # stream continues past numSigs
+    }
+    # negative key in the middle of a cluster and an early empty slot
+    b = bytearray(img)
+    b[24 + 24 * 100:24 + 24 * 100 + 8] = struct.pack("<q", -5)
+    b[24 + 24 * 2000:24 + 24 * 2000 + 8] = struct.pack("<q", synth.EMPTY_KEY + 12345)
+    variants["negative+hole"] = bytes(b)
+    for name, im in variants.items():
+        ora = oracle.run(im, sb, off, lookup_mode=1, min_hits=2)
+        ora0 = oracle.run(im, sb, off, lookup_mode=0, min_hits=2)
+        assert ora["hits"].tobytes() == ora0["hits"].tobytes(), name
+        with hp.SignatureTable.from_bytes(im) as tab, tab.scan(sb, off, hp.Params(min_hits=2, counters=True)) as r:
+            assert_same_records(r, ora, "table " + name)
+            assert r.stats["slots_inspected"] == ora["slots_inspected"], name
+
+
+def test_errors(hp, native):
+    import ctypes as C
+    with pytest.raises(native.KmerGutsNativeError):
+        hp.SignatureTable.from_bytes(b"\x00" * 10)
+    bad = np.zeros(48, dtype=np.uint8)
+    bad[0] = 1; bad[8] = 16                                       # entrySize 16
+    with pytest.raises(native.KmerGutsNativeError):
+        hp.SignatureTable.from_bytes(bad)
+    from kmergutsjava_amd import synth
+    rec, _, _ = synth.random_table(101, 0.5, 1)
+    with hp.SignatureTable.from_bytes(synth.table_image(rec)) as tab:
+        with pytest.raises(native.KmerGutsNativeError) as ei:
+            tab.scan(b"ACGT" * 10, np.array([0, 40]), hp.Params(min_hits=1))
+        assert ei.value.code == -6
+
+
+def test_determinism_and_device_input(hp, oracle):
+    from kmergutsjava_amd import synth
+    rec, placed, keys = synth.random_table(200003, 0.5, 31)
+    img = _img(rec)
+    seq, off = synth.dna_mix_config(300_000)
+    sb = plant(seq.numpy().tobytes(), off, keys.tolist(), every=90)
+    ora = oracle.run(img, sb, off, lookup_mode=1)
+    d = torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda()
+    with hp.SignatureTable.from_bytes(img) as tab:
+        with tab.scan(sb, off) as r1, tab.scan(None, off, device_ptr=d.data_ptr()) as r2:
+            assert_same_records(r1, ora, "mix host input")
+            assert_same_records(r2, ora, "mix device input")
+            assert r1.hits().tobytes() == r2.hits().tobytes()
