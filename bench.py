@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the kmer_guts hot path on MI355X.
+
+One "step" = one pass of the hot path (6-frame translate -> base-20 encode -> signature-table
+probe -> ordered hit compaction -> CALL / OTU aggregation) over one batch of synthetic contigs
+that is already resident in HBM, through the C ABI (kg_scan_device).  Workload = BASELINE.json
+configs[2] (== the metric's configuration): 1 Gbp metagenome-like contig mix against a full-size
+KmerGuts signature table.  With N ranks every rank scans its own 1 Gbp
+shard against its own replica of the table (weak scaling) and the CALL / OTU records are gathered
+to rank 0 with RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--total-bp", type=int, default=1_000_000_000, help="contig bases per GPU")
+    ap.add_argument("--num-sigs", type=int, default=1_400_303_159, help="signature table slots (x 24 B)")
+    ap.add_argument("--load", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-bp", type=int, default=10_000_000)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from kmergutsjava_amd import hotpath, synth
+    from kmergutsjava_amd import distributed as kd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- synthetic table (replicated) and this rank's contig shard, generated in HBM ----
+    t0 = time.time()
+    rec, placed, keys = synth.random_table(args.num_sigs, args.load, 202, dev)
+    del keys
+    torch.cuda.synchronize()
+    log("[bench] table: %d slots, %d signatures, %.1f GB, built in %.1f s" %
+        (args.num_sigs, placed, args.num_sigs * 24 / 1e9, time.time() - t0))
+    tab = hotpath.SignatureTable.from_device_ptr(rec.data_ptr(), args.num_sigs, local_rank, keepalive=rec)
+
+    lens = synth.contig_mix_lengths(args.total_bp, 301)                 # same length mix, different bases per rank
+    off = synth.offsets_of(lens)
+    seq = synth.random_dna(int(off[-1]), 302, dev, start=rank * args.total_bp)
+    torch.cuda.synchronize()
+    log("[bench] rank %d: %d contigs, %d bp" % (rank, len(lens), int(off[-1])))
+
+    params = hotpath.Params()                      # reference defaults: -m 5 -g 200
+    gather_dev = dev
+
+    def step():
+        with tab.scan(None, off, params, device_ptr=seq.data_ptr()) as r:
+            st = r.stats
+            if world > 1:
+                local = {"calls": r.calls(), "container_call_start": r.container_call_start(), "otu": r.otu()}
+                kd.gather_records(local, np.arange(len(lens)) * world + rank, len(lens) * world, 6, gather_dev)
+            else:
+                r.calls(); r.otu()                 # the records the report needs leave HBM
+            return st
+
+    # one instrumented launch: algorithmic bytes per residue, not timed
+    with tab.scan(None, off, hotpath.Params(counters=True), device_ptr=seq.data_ptr()) as r:
+        cst = r.stats
+    residues = cst["residues"]
+    p_bar = cst["slots_inspected"] / residues
+    h_bar = cst["n_hits"] / residues
+    b_alg = 0.5 + 24.0 * p_bar + 24.0 * h_bar
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t1 = time.perf_counter()
+    scan_ms, total_ms, agg_ms, order_ms = [], [], [], []
+    hits = calls = 0
+    for _ in range(args.steps):
+        st = step()
+        scan_ms.append(st["ms_scan"]); total_ms.append(st["ms_total"])
+        agg_ms.append(st["ms_aggregate"]); order_ms.append(st["ms_order"])
+        hits, calls = st["n_hits"], st["n_calls"]
+        assert st["scan_launches"] == 1, "staging buffer resized inside the timed region"
+    barrier()
+    elapsed = time.perf_counter() - t1
+
+    tot = torch.tensor([elapsed, float(residues), float(hits)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot[:1].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot[1:].clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, residues_all, hits_all = float(mx[0]), float(sm[0]), float(sm[1])
+    else:
+        residues_all, hits_all = float(residues), float(hits)
+
+    if rank == 0:
+        ms_scan = float(np.mean(scan_ms))
+        achieved = b_alg * residues / (ms_scan * 1e-3) / 1e9          # GB/s, algorithmic bytes / scan-kernel time
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")        # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("total_bp") == args.total_bp and tj.get("num_sigs") == args.num_sigs:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "amino-acid residues/sec scanned (and hits/sec) on 1 Gbp synthetic, 1/2/4/8 MI355X",
+            "value": residues_all * args.steps / elapsed,
+            "unit": "residues/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "hits_per_s": hits_all * args.steps / elapsed,
+            "config": {"workload": "1 Gbp contig mix (0.5 kbp..1.024 Mbp, uniform ACGT) per GPU, 6-frame translate + "
+                                   "8-mer lookup vs %d-slot signature table (%.1f GB, load %.2f), -m 5 -g 200"
+                                   % (args.num_sigs, args.num_sigs * 24 / 1e9, args.load),
+                       "total_bp_per_gpu": int(off[-1]), "contigs_per_gpu": int(len(lens)),
+                       "num_sigs": args.num_sigs, "residues_per_gpu": int(residues),
+                       "hits_per_gpu": int(hits), "calls_per_gpu": int(calls),
+                       "parallelism": "contig shards x%d, table replicated" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "kg::scan_kernel<false,false>", "kernel_ms": ms_scan,
+                         "alg_bytes_per_residue": b_alg, "slots_per_residue": p_bar, "hits_per_residue": h_bar,
+                         "residues_per_launch": int(residues)},
+            "stage_ms": {"scan": ms_scan, "order": float(np.mean(order_ms)), "aggregate": float(np.mean(agg_ms)),
+                         "device_total": float(np.mean(total_ms))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, rec, seq, off)
+        print(json.dumps(out), flush=True)
+
+    tab.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, rec, seq, off):
+    """The C restatement of the reference algorithm (oracle/, literal sorted merge-join, 1 thread)
+    timed on the first contigs of the same workload against the same table."""
+    import struct
+    from oracle import kgo
+    kgo.build()
+    n = int(np.searchsorted(off, args.cpu_sample_bp, side="right"))
+    n = max(1, min(n, len(off) - 1))
+    sample_off = off[:n + 1].copy()
+    sample = seq[:int(sample_off[-1])].cpu().numpy()
+    t0 = time.time()
+    host = torch.empty(24 + args.num_sigs * 24, dtype=torch.uint8)
+    host[:24] = torch.frombuffer(bytearray(struct.pack("<qqq", args.num_sigs, 24, 1)), dtype=torch.uint8)
+    host[24:].view(torch.int32).view(args.num_sigs, 6).copy_(rec)
+    log("[bench] cpu_baseline: table copied to host in %.1f s" % (time.time() - t0))
+    t0 = time.time()
+    o = kgo.run(host.numpy(), sample, sample_off, lookup_mode=0)
+    wall = time.time() - t0
+    phases = o["t_prepare"] + o["t_lookup"] + o["t_group"]
+    log("[bench] cpu_baseline: %d residues in %.1f s (prepare %.1f, lookup %.1f, group %.1f)" %
+        (o["residues"], wall, o["t_prepare"], o["t_lookup"], o["t_group"]))
+    return {"value": o["residues"] / phases, "unit": "residues/s", "cores": 1, "kind": "port",
+            "sample": "first %d contigs (%d bp, %d residues, %d query k-mers: one <=20 M-k-mer batch) of the same "
+                      "contig mix against the same table; C restatement of the reference's materialise -> sort by "
+                      "(value %% numSigs, value) -> streamed merge-join -> gatherHits, single thread"
+                      % (n, int(sample_off[-1]), o["residues"], o["windows_valid"]),
+            "seconds": phases, "cpu": _cpu_model(), "host_threads_available": os.cpu_count(),
+            "phases_s": {"preparation": o["t_prepare"], "lookup": o["t_lookup"], "grouping": o["t_group"]}}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

@@ -105,7 +105,8 @@ typedef struct kg_result kg_result;
 int kg_table_open(const char *path, int device, kg_table **out);
 /* Same from a file image in host memory (the host gunzips kmer.table.mem_map.gz, KGJ:750-753). */
 int kg_table_from_memory(const void *image, size_t nbytes, int device, kg_table **out);
-/* Adopt num_sigs 24-byte entries that already sit in device memory (not copied, not freed). */
+/* Adopt num_sigs 24-byte entries that already sit in device memory (not copied, not freed; must stay
+ * unchanged while the table lives).  Synchronises the device once before reading them. */
 int kg_table_from_device(const void *d_entries, int64_t num_sigs, int device, kg_table **out);
 /* header fields (KmerMemoryInfo, KGJ:1194-1198) and the number of occupied slots */
 int kg_table_info(const kg_table *t, int64_t *num_sigs, int64_t *entry_size, int64_t *version, int64_t *occupied);
@@ -117,7 +118,8 @@ void kg_table_close(kg_table *t);
  *      hands them to prepareQuery (KGJ:780-783); offsets[n_seqs+1] in host memory. ---- */
 int kg_scan(kg_table *t, const kg_params *p, const uint8_t *seq, const int64_t *offsets,
             int64_t n_seqs, kg_result **out);
-/* same with the sequence bytes already in device memory (offsets stay on the host) */
+/* same with the sequence bytes already in device memory (offsets stay on the host).  The bytes must be
+ * complete before the call: the library works on its own non-blocking stream. */
 int kg_scan_device(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64_t *offsets,
                    int64_t n_seqs, kg_result **out);
 
@@ -131,6 +133,7 @@ const kg_otu  *kg_result_otu(kg_result *r);                  /* n_seqs          
 /* Device views (valid until kg_result_free) for callers that keep working in HBM. */
 const void    *kg_result_device_hits(const kg_result *r);
 const void    *kg_result_device_calls(const kg_result *r);
+const void    *kg_result_device_otu(const kg_result *r);
 void kg_result_free(kg_result *r);
 
 const char *kg_last_error(void);

@@ -23,7 +23,7 @@ EXPORTS = (
     "kg_table_open", "kg_table_from_memory", "kg_table_from_device", "kg_table_info", "kg_table_close",
     "kg_scan", "kg_scan_device", "kg_result_stats", "kg_result_hits", "kg_result_container_hit_start",
     "kg_result_calls", "kg_result_container_call_start", "kg_result_otu", "kg_result_device_hits",
-    "kg_result_device_calls", "kg_result_free", "kg_last_error", "kg_version",
+    "kg_result_device_calls", "kg_result_device_otu", "kg_result_free", "kg_last_error", "kg_version",
 )
 
 HIT_DTYPE = np.dtype([("container", "<u4"), ("from0InProt", "<i4"), ("oI", "<i4"),
@@ -82,7 +82,7 @@ def load() -> C.CDLL:
     lib.kg_result_stats.argtypes = [vp, C.POINTER(KgStats)]
     for name in ("kg_result_hits", "kg_result_container_hit_start", "kg_result_calls",
                  "kg_result_container_call_start", "kg_result_otu", "kg_result_device_hits",
-                 "kg_result_device_calls"):
+                 "kg_result_device_calls", "kg_result_device_otu"):
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = vp
     lib.kg_result_free.argtypes = [vp]

@@ -1,0 +1,298 @@
+// kg_aggregate.hpp -- gatherHits (KGJ:457-514) + processSetOfHits (KGJ:385-455) on gfx950.
+//
+// One wavefront owns one HitContainer (its position-ordered hit records are contiguous in
+// hits[]).  The reference's state machine is sequential per container; the wave runs it with
+// wave-uniform (scalar) control flow over 64-record chunks that are loaded coalesced:
+//
+//   * The reference's "hits" list is always the accepted records inside one index range
+//     [lo, last] of the container (it is only ever cleared or cut down to its last two members),
+//     so the list is (lo, last, prev, cnt) plus one "accepted" byte per record (the -O order
+//     constraint, KGJ:490-494, and the 39 998 cap, KGJ:496, reject records).
+//   * FAST path (no -O, list far from the cap): every record is accepted, so the only records at
+//     which the machine does more than "append" are those preceded by a gap > maxGap
+//     (KGJ:477-484) or carrying the same function index as their predecessor (KGJ:503-508).  Both
+//     conditions are per-record facts; one ballot finds them and the scalar loop visits only those.
+//   * SLOW path (-O, or the list could reach the cap inside the chunk): record by record.
+//   * processSetOfHits walks the list in 64-record chunks; the float32 weight sum is added in list
+//     order (KGJ:394) by visiting the voters' lanes in ascending order.
+//
+// Calls per container are counted first (EMIT = false), prefix-summed, then written (EMIT = true)
+// so that calls[] is in the reference's emission order without atomics.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kmerguts_hip.h"
+
+namespace kg {
+
+struct AggParams { int32_t min_hits, min_weighted_hits, max_gap, order_constraint; };
+
+struct CallSpan { uint32_t lo, last_hit; };   // global hit indices: first record of the called set, last voter
+
+struct AggState {                 // everything here is wave-uniform
+    uint32_t lo, last, prev;      // hit indices of the list's first / last / second-to-last member
+    int32_t last_pos, last_fI, last_avg, prev_fI;
+    int32_t cnt;                  // list size
+    int32_t currentFI;
+    uint32_t ncalls;
+};
+
+__device__ __forceinline__ int32_t rl(int32_t v, int k) { return __builtin_amdgcn_readlane(v, k); }
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// processSetOfHits (KGJ:385-455) on the list [s.lo .. s.last].  chunk grid is anchored at `begin`
+// so that the chunk the caller is working on (cur_base, membership bits cur_mask) can be taken from
+// registers instead of acc[].
+template <bool EMIT>
+__device__ __forceinline__ void process_set(const kg_hit *__restrict__ h, const uint8_t *__restrict__ acc, uint32_t begin,
+                                            const AggParams &p, AggState &s, uint32_t cur_base, uint64_t cur_mask,
+                                            uint32_t container, uint32_t call_at, kg_call *calls, CallSpan *spans,
+                                            bool allow_carry)
+{
+    const int lane = threadIdx.x & 63;
+    int32_t fICount = 0;
+    float weighted = 0.f;
+    uint32_t lastHit = s.lo;
+    const uint32_t c0 = begin + ((s.lo - begin) & ~63u);
+    for (uint32_t b = c0; b <= s.last; b += 64) {                       // KGJ:390-396
+        const uint32_t i = b + lane;
+        const bool in = i >= s.lo && i <= s.last;
+        int32_t fI = 0;
+        float wt = 0.f;
+        bool mem = false;
+        if (in) {
+            fI = h[i].fI;
+            wt = h[i].functionWt;
+            mem = (b == cur_base) ? ((cur_mask >> lane) & 1ull) != 0 : acc[i] != 0;
+        }
+        uint64_t m = __ballot(in && mem && fI == s.currentFI);
+        if (m) {
+            fICount += (int32_t)__popcll(m);
+            lastHit = b + 63u - (uint32_t)__builtin_clzll(m);
+            const int32_t wbits = __float_as_int(wt);
+            while (m) {                                                 // float32 sum in list order (KGJ:394)
+                const int k = __builtin_ctzll(m);
+                m &= m - 1;
+                weighted += __int_as_float(rl(wbits, k));
+            }
+        }
+    }
+    if (fICount >= p.min_hits && weighted >= (float)p.min_weighted_hits) {      // KGJ:397
+        if (EMIT && lane == 0) {
+            kg_call c;
+            c.container = container;
+            c.start = h[s.lo].from0InProt;                              // KGJ:399: first record of the set, any fI
+            c.end = h[lastHit].from0InProt + (KG_K - 1);                // KGJ:400
+            c.count = fICount; c.fI = s.currentFI; c.weightedHits = weighted;
+            calls[call_at + s.ncalls] = c;
+            CallSpan sp; sp.lo = s.lo; sp.last_hit = lastHit;
+            spans[call_at + s.ncalls] = sp;
+        }
+        s.ncalls++;
+    }
+    // KGJ:441-453: keep the last two members if they open a new function, else clear
+    if (allow_carry && s.cnt >= 2 && s.prev_fI != s.currentFI && s.prev_fI == s.last_fI) {
+        s.currentFI = s.last_fI;
+        s.lo = s.prev;
+        s.cnt = 2;
+    } else {
+        s.cnt = 0;
+    }
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restrict__ hits, const int64_t *__restrict__ chs,
+                                                         uint32_t n_cont, AggParams p, uint8_t *acc, uint32_t *call_cnt,
+                                                         const uint32_t *call_off, kg_call *calls, CallSpan *spans)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t c = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (c >= n_cont) return;
+    if (EMIT && call_cnt[c] == 0) return;          // nothing to write; acc[] was filled by the counting pass
+    const uint32_t begin = (uint32_t)chs[c], end = (uint32_t)chs[c + 1];
+    const uint32_t call_at = EMIT ? call_off[c] : 0;
+
+    AggState s;
+    s.lo = s.last = s.prev = begin;
+    s.last_pos = s.last_fI = s.last_avg = s.prev_fI = 0;
+    s.cnt = 0; s.currentFI = 0; s.ncalls = 0;
+    int32_t carry_pos = 0, carry_fI = 0;            // fields of the record before this chunk
+    uint32_t tail_base = 0xFFFFFFFFu;               // last chunk and its membership bits, for the final flush
+    uint64_t tail_mask = 0;
+
+    for (uint32_t base = begin; base < end; base += 64) {
+        const int n = (int)min(64u, end - base);
+        const uint32_t i = base + lane;
+        int32_t pos = 0, fI = 0, avg = 0;
+        if (lane < n) { pos = hits[i].from0InProt; fI = hits[i].fI; avg = hits[i].avgOffFromEnd; }
+        uint64_t accmask;
+
+        // the fast path needs every record of the chunk to be accepted and the list's last member to be
+        // the record just before the chunk (after a cap overflow the list can end far behind)
+        const bool fast = !p.order_constraint && s.cnt + n < KG_MAX_HITS_PER_SEQ - 2 &&
+                          (s.cnt == 0 || s.last + 1 == base);
+        if (fast) {
+            accmask = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+            int32_t ppos = __shfl_up(pos, 1), pfI = __shfl_up(fI, 1);
+            if (lane == 0) { ppos = carry_pos; pfI = carry_fI; }
+            const bool first = i == begin;
+            // KGJ:477-478 with Java int wrap-around: last.from0InProt + maxGap < ph.from0InProt
+            const bool gapf = !first && (int32_t)((uint32_t)ppos + (uint32_t)p.max_gap) < pos;
+            const bool eqf = !first && fI == pfI;
+            uint64_t ev = __ballot(lane < n && (gapf || eqf));
+            const uint64_t gapm = __ballot(gapf), eqm = __ballot(eqf);
+            int k0 = 0;
+            while (ev) {
+                const int k = __builtin_ctzll(ev);
+                ev &= ev - 1;
+                if (k > k0) {                                           // records k0..k-1: plain appends
+                    if (s.cnt == 0) { s.currentFI = rl(fI, k0); s.lo = base + k0; }     // KGJ:486-488
+                    s.cnt += k - k0;
+                }
+                const int32_t fk = rl(fI, k);
+                const uint32_t ik = base + (uint32_t)k;
+                if (s.cnt > 0 && ((gapm >> k) & 1)) {                                   // KGJ:477-484
+                    if (s.cnt >= p.min_hits) {
+                        s.last = ik - 1;
+                        // no carry is possible here: a pair of equal, non-current fI at the end of the list
+                        // would have fired the pair rule when its second record was appended
+                        process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, false);
+                    } else {
+                        s.cnt = 0;
+                    }
+                }
+                if (s.cnt == 0) { s.currentFI = fk; s.lo = ik; }                         // KGJ:486-488
+                s.cnt++;                                                                 // KGJ:496-497
+                if (s.cnt > 1 && s.currentFI != fk && ((eqm >> k) & 1)) {                // KGJ:503-508
+                    s.last = ik; s.prev = ik - 1; s.last_fI = fk; s.prev_fI = fk;
+                    process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true);
+                }
+                k0 = k + 1;
+            }
+            if (n > k0) {
+                if (s.cnt == 0) { s.currentFI = rl(fI, k0); s.lo = base + k0; }
+                s.cnt += n - k0;
+            }
+            // hand-over state for a following chunk (which may take the slow path)
+            if (s.cnt > 0) {
+                s.last = base + n - 1;
+                s.last_pos = rl(pos, n - 1); s.last_fI = rl(fI, n - 1); s.last_avg = rl(avg, n - 1);
+                if (s.cnt > 1) { s.prev = s.last - 1; s.prev_fI = n >= 2 ? rl(fI, n - 2) : carry_fI; }
+            }
+        } else {
+            accmask = 0;
+            for (int k = 0; k < n; k++) {
+                const int32_t pk = rl(pos, k), fk = rl(fI, k), ak = rl(avg, k);
+                const uint32_t ik = base + (uint32_t)k;
+                if (s.cnt > 0 && (int32_t)((uint32_t)s.last_pos + (uint32_t)p.max_gap) < pk) {      // KGJ:477-484
+                    if (s.cnt >= p.min_hits)
+                        process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true);
+                    else
+                        s.cnt = 0;
+                }
+                if (s.cnt == 0) s.currentFI = fk;                                                    // KGJ:486-488
+                bool ok = !p.order_constraint || s.cnt == 0;
+                if (!ok) {                                                                           // KGJ:490-494
+                    const int32_t d = (int32_t)((uint32_t)(pk - s.last_pos) - (uint32_t)(s.last_avg - ak));
+                    const int32_t ad = d < 0 ? (int32_t)(0u - (uint32_t)d) : d;                     // Math.abs(int)
+                    ok = fk == s.last_fI && ad <= 20;
+                }
+                if (ok) {
+                    if (s.cnt < KG_MAX_HITS_PER_SEQ - 2) {                                           // KGJ:496-497
+                        if (s.cnt == 0) { s.lo = ik; s.prev = ik; s.prev_fI = fk; }
+                        else { s.prev = s.last; s.prev_fI = s.last_fI; }
+                        s.last = ik; s.last_pos = pk; s.last_fI = fk; s.last_avg = ak;
+                        s.cnt++;
+                        accmask |= 1ull << k;
+                    }
+                    if (s.cnt > 1 && s.currentFI != fk && s.prev_fI == s.last_fI)                    // KGJ:503-508
+                        process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true);
+                }
+            }
+        }
+        if (!EMIT && lane < n) acc[i] = (uint8_t)((accmask >> lane) & 1ull);
+        carry_pos = rl(pos, n - 1);
+        carry_fI = rl(fI, n - 1);
+        tail_base = base;
+        tail_mask = accmask;
+    }
+    if (s.cnt >= p.min_hits) {                                                                       // KGJ:511-513
+        process_set<EMIT>(hits, acc, begin, p, s, tail_base, tail_mask, c, call_at, calls, spans, true);
+    }
+    if (!EMIT && lane == 0) call_cnt[c] = s.ncalls;
+}
+
+// ccs[c] = call_off[c] widened, plus sentinel
+__global__ void call_starts_kernel(const uint32_t *call_off, uint64_t n_cont, const uint64_t *total, int64_t *ccs)
+{
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_cont) return;
+    ccs[c] = c == n_cont ? (int64_t)*total : (int64_t)call_off[c];
+}
+
+// OTU vote (KGJ:413-439), one wave per sequence: replay the voters of every CALL of the sequence in
+// emission order against the 5-entry buffer that persists across the sequence's containers
+// (KGJ:528, 540).  The buffer lives in wave-uniform registers; the voters of one chunk are visited
+// in ascending lane order.
+__global__ __launch_bounds__(256) void otu_wave_kernel(const kg_hit *__restrict__ hits, const uint8_t *__restrict__ acc,
+                                                       const kg_call *__restrict__ calls, const CallSpan *__restrict__ spans,
+                                                       const int64_t *__restrict__ ccs, uint32_t n_seqs, uint32_t per,
+                                                       kg_otu *otu)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t s = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (s >= n_seqs) return;
+    int32_t n = 0;
+    int32_t cnt[KG_OI_BUFSZ] = {0, 0, 0, 0, 0}, oi[KG_OI_BUFSZ] = {0, 0, 0, 0, 0};
+    const int64_t c0 = ccs[(uint64_t)s * per], c1 = ccs[(uint64_t)(s + 1) * per];
+    for (int64_t c = c0; c < c1; c++) {
+        const int32_t fI = calls[c].fI;
+        const CallSpan sp = spans[c];
+        for (uint32_t b = sp.lo; b <= sp.last_hit; b += 64) {
+            const uint32_t i = b + lane;
+            bool vote = false;
+            int32_t o = 0;
+            if (i <= sp.last_hit) { vote = acc[i] != 0 && hits[i].fI == fI; o = hits[i].oI; }
+            uint64_t m = __ballot(vote);
+            while (m) {
+                const int k = __builtin_ctzll(m);
+                m &= m - 1;
+                const int32_t ok = rl(o, k);
+                int j = n;                                              // KGJ:416-417 linear search
+#pragma unroll
+                for (int t = KG_OI_BUFSZ - 1; t >= 0; t--)
+                    if (t < n && oi[t] == ok) j = t;
+                if (j == n) {                                           // KGJ:418-427
+                    if (n == KG_OI_BUFSZ) j--; else n++;
+#pragma unroll
+                    for (int t = 0; t < KG_OI_BUFSZ; t++)
+                        if (t == j) { oi[t] = ok; cnt[t] = 1; }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < KG_OI_BUFSZ; t++)
+                        if (t == j) cnt[t]++;
+                }
+#pragma unroll
+                for (int t = KG_OI_BUFSZ - 1; t >= 1; t--) {            // KGJ:432-437 bubble toward the front
+                    if (j == t && cnt[t - 1] <= cnt[t]) {
+                        int32_t tc = cnt[t - 1], to = oi[t - 1];
+                        cnt[t - 1] = cnt[t]; oi[t - 1] = oi[t];
+                        cnt[t] = tc; oi[t] = to;
+                        j = t - 1;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        kg_otu r;
+        r.n = n;
+#pragma unroll
+        for (int k = 0; k < KG_OI_BUFSZ; k++) { r.count[k] = k < n ? cnt[k] : 0; r.oI[k] = k < n ? oi[k] : 0; }
+        otu[s] = r;
+    }
+}
+
+}  // namespace kg

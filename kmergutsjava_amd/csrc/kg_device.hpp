@@ -59,19 +59,6 @@ struct TableView {
     uint64_t magic;      // floor(2^64 / num_sigs)
 };
 
-struct ScanArgs {
-    TableView tab;
-    const uint8_t *seq;
-    const BlockDesc *blocks;
-    uint32_t n_blocks;
-    uint32_t *counts;            // hits per (virtual row); DNA 6 per block, AA 1 per block
-    uint32_t *block_stage_base;  // first staging record of the block
-    kg_hit *stage;               // staging area, block-granular placement by atomic cursor
-    unsigned long long *cursor;  // staging cursor
-    uint64_t stage_cap;
-    unsigned long long *ctr;     // [0] windows_valid, [1] slots_inspected (KG_F_COUNTERS)
-};
-
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_sync()
 {
@@ -138,6 +125,7 @@ __device__ __forceinline__ int first_stop(const Tags16 &x, uint32_t fp, bool *is
 }
 
 struct Entry { int64_t key; int32_t oI, avg, fI; float wt; };
+struct Payload { int32_t oI, avg, fI; float wt; };
 
 __device__ __forceinline__ Entry load_entry(const TableView &t, uint64_t slot)
 {
@@ -147,25 +135,6 @@ __device__ __forceinline__ Entry load_entry(const TableView &t, uint64_t slot)
     e.key = (int64_t)(((uint64_t)a.y << 32) | a.x);
     e.oI = (int32_t)b.x; e.avg = (int32_t)b.y; e.fI = (int32_t)c.x; e.wt = __uint_as_float(c.y);
     return e;
-}
-
-// Generic probe from slot s (KGJ:944-1034 semantics: walk forward until the k-mer, an empty
-// slot or the end of the stream; never wrap).  Returns the matching slot or kNotFound and
-// the slot at which the walk stopped (for the inspected-entries counter).
-__device__ __noinline__ uint64_t probe_slow(const TableView &t, uint64_t v, uint32_t fp, uint64_t s,
-                                            Entry *hit, uint64_t *stop_slot)
-{
-    for (;;) {
-        if (s >= t.limit) { *stop_slot = t.limit; return kNotFound; }
-        Tags16 x = load_tags(t.tags + s);
-        bool emp;
-        int i = first_stop(x, fp, &emp);
-        if (i == 16) { s += 16; continue; }
-        if (emp) { *stop_slot = s + i; return kNotFound; }
-        Entry e = load_entry(t, s + i);
-        if (e.key == (int64_t)v) { *hit = e; *stop_slot = s + i; return s + i; }
-        s += i + 1;
-    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -211,18 +180,35 @@ struct __attribute__((aligned(16))) WaveLdsAa {
 };
 
 // ---------------------------------------------------------------------------------------
-// The scan kernel.  ROWS = 6 (DNA) or 1 (AA).
-template <bool AA, bool COUNTERS>
-__global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(ScanArgs a)
+// The scan kernel.  ROWS = 6 (DNA) or 1 (AA).  Waves are persistent and stride over the blocks.
+//
+// All pointers are direct kernel arguments (global address space: global_load, counted vmcnt);
+// pointers inside a by-value struct would be generic and compile to flat_load + vmcnt(0).
+//
+// Hit staging: a wave reserves staging records in chunks of `stage_chunk` from one global cursor
+// and hands them out to its successive blocks (one returning atomic per ~chunk/hits-per-block
+// blocks instead of one per block; a single word sustains only ~90 returning atomics per us).
+// The unused tail of a chunk is a hole; block_stage_base[] says where each block's records are.
+// RPG = rows probed together by one lane (memory-level parallelism per lane vs registers per wave);
+// a block's ROWS/RPG row groups are staged independently (block_stage_base has one entry per group).
+template <bool AA, bool COUNTERS, int RPG>
+__global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
+    const uint8_t *__restrict__ entries, const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, uint64_t magic,
+    const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t n_blocks, uint32_t *__restrict__ counts,
+    uint32_t *__restrict__ block_stage_base, kg_hit *__restrict__ stage, unsigned long long *cursor, uint64_t stage_cap,
+    uint32_t stage_chunk, unsigned long long *ctr)
 {
     constexpr int ROWS = AA ? 1 : 6;
+    constexpr int NG = ROWS / RPG;
+    static_assert(ROWS % RPG == 0, "RPG must divide the row count");
     __shared__ WaveLdsDna lds_dna[AA ? 1 : kWavesPerWG];
     __shared__ WaveLdsAa lds_aa[AA ? kWavesPerWG : 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerWG + wave);
     const uint32_t n_waves = gridDim.x * kWavesPerWG;
-    const TableView tab = a.tab;
+    TableView tab;
+    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic;
 
     WaveLdsDna &ld = lds_dna[AA ? 0 : wave];
     WaveLdsAa &la = lds_aa[AA ? wave : 0];
@@ -235,25 +221,21 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(ScanArgs a)
     wave_sync();
 
     unsigned long long ctr_valid = 0, ctr_slots = 0;
+    unsigned long long res_at = 0, res_end = 0;          // this wave's staging reservation (uniform)
 
-    for (uint32_t it = wave_global; it < a.n_blocks; it += n_waves) {
-        const BlockDesc bd = a.blocks[it];
+    for (uint32_t it_v = wave_global; it_v < n_blocks; it_v += n_waves) {
+        const uint32_t it = __builtin_amdgcn_readfirstlane(it_v);
+        const BlockDesc bd = blocks[it];
         const uint64_t soff = bd.soff;
         const uint32_t L = bd.len, j = bd.j, nk = bd.nk;
-
-        uint64_t val[ROWS];      // encodedKmer (KGJ:274-292)
-        bool valid[ROWS];
-        int32_t pos[ROWS];       // from0InProt
-        uint32_t vrow[ROWS];     // index into counts[]
-        uint32_t cont[ROWS];     // HitContainer id (KGJ:907-911 order)
 
         if (AA) {
             // ---- protein: windows i = 64j + lane, queried iff i < len - 8 (KGJ:912: i < pIseq.length - K)
             const uint32_t w0 = j * kAaWinPerBlock;
             const uint32_t nload = min(71u, L - w0);
             for (uint32_t q = lane; q < 72; q += 64) {
-                uint32_t c = q < nload ? a.seq[soff + w0 + q] : 0u;
-                la.code[q] = la.lut[c];          // own lane's write is read back by the same lane
+                uint32_t c = q < nload ? seq[soff + w0 + q] : 0u;
+                la.code[q] = la.lut[c];
             }
             wave_sync();
             for (uint32_t q = lane; q < 68; q += 64) {
@@ -262,20 +244,12 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(ScanArgs a)
                 la.H4[q] = ok ? c0 * 8000u + c1 * 400u + c2 * 20u + c3 : kInvalid;
             }
             wave_sync();
-            uint32_t hi = la.H4[lane], lo = la.H4[lane + 4];
-            uint32_t i = w0 + lane;
-            valid[0] = (hi != kInvalid) & (lo != kInvalid) & ((uint64_t)i + 8 < (uint64_t)L);
-            val[0] = (uint64_t)hi * 160000ull + lo;
-            pos[0] = (int32_t)i;
-            vrow[0] = it;
-            cont[0] = bd.seq;
-            wave_sync();   // LDS is reused by the next block
         } else {
             // ---- DNA: stage 215 bases, derive codon codes for both strands, then 4-codon half codes
             const uint32_t ts = j * kDnaPosPerBlock;
             const uint32_t nload = min(215u, L - ts);
             for (uint32_t q = lane; q < 232; q += 64) {
-                uint32_t c = q < nload ? a.seq[soff + ts + q] : (uint32_t)'N';
+                uint32_t c = q < nload ? seq[soff + ts + q] : (uint32_t)'N';
                 ld.bc[q] = (uint8_t)dna_code(c);
             }
             wave_sync();
@@ -300,127 +274,189 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(ScanArgs a)
                 ld.G[q] = okr ? r3 * 8000u + r2 * 400u + r1 * 20u + r0 : kInvalid;
             }
             wave_sync();
-            const uint32_t vbase = 6u * bd.ibase;
-#pragma unroll
-            for (int f = 0; f < 3; f++) {
-                const uint32_t pl = 3u * lane + f;
-                uint32_t h0 = ld.H[pl], h1 = ld.H[pl + 12];
-                uint32_t g0 = ld.G[pl], g1 = ld.G[pl + 12];
-                // '+' strand: frame f (block start is a multiple of 3), residue index 64j + lane
-                valid[f] = (h0 != kInvalid) & (h1 != kInvalid);
-                val[f] = (uint64_t)h0 * 160000ull + h1;
-                pos[f] = (int32_t)(j * 64u + lane);
-                vrow[f] = vbase + (uint32_t)f * nk + j;
-                cont[f] = bd.seq * 6u + (uint32_t)f;
-                // '-' strand: the window over forward bases p..p+23 starts at reverse-complement base
-                // b' = L-24-p, i.e. frame b'%3, residue b'/3 (KGJ:1068-1072).  24 % 3 == 0 and ts % 3 == 0,
-                // so the frame depends on f only.
-                const uint32_t fr = (L - (uint32_t)f) % 3u;
-                valid[3 + f] = (g0 != kInvalid) & (g1 != kInvalid);
-                val[3 + f] = (uint64_t)g1 * 160000ull + g0;
-                pos[3 + f] = (int32_t)((L - 24u - (uint32_t)f - ts) / 3u) - (int32_t)lane;
-                vrow[3 + f] = vbase + (3u + fr) * nk + (nk - 1u - j);
-                cont[3 + f] = bd.seq * 6u + 3u + fr;
-            }
-            wave_sync();   // LDS is reused by the next block
         }
 
-        // ---- probe: home slot, 16 tags per load, records touched only on a fingerprint match
-        uint64_t slot[ROWS];
-        uint32_t fp[ROWS];
-        Tags16 tg[ROWS];
+        const uint32_t vbase = 6u * bd.ibase;
+        for (int g = 0; g < NG; g++) {
+            // ---- encodedKmer (KGJ:274-292) of this group's rows out of the half codes
+            uint64_t val[RPG];
+            bool valid[RPG];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            slot[r] = home_slot(val[r], tab);
-            fp[r] = tag_of(val[r]);
-            if (COUNTERS && valid[r]) ctr_valid++;          // query k-mers (KGJ:913-920)
-            valid[r] = valid[r] && slot[r] < tab.limit;     // beyond the stream: EOF, not found, nothing inspected
-            if (valid[r]) tg[r] = load_tags(tab.tags + slot[r]);
-        }
-        // state per row: 0 = resolved, 1 = candidate at cand[r], 2 = continue with the generic walk
-        int st[ROWS];
-        uint64_t cand[ROWS];
-        uint64_t stop[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            st[r] = 0; cand[r] = kNotFound; stop[r] = slot[r];
-            if (valid[r]) {
-                bool emp;
-                int i = first_stop(tg[r], fp[r], &emp);
-                if (i == 16) { st[r] = 2; cand[r] = slot[r] + 16; }
-                else if (emp) { stop[r] = slot[r] + (uint64_t)i; }
-                else { st[r] = 1; cand[r] = slot[r] + (uint64_t)i; }
-            }
-        }
-        Entry ent[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++)
-            if (st[r] == 1) ent[r] = load_entry(tab, cand[r]);
-        bool found[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            found[r] = false;
-            if (st[r] == 1) {
-                if (ent[r].key == (int64_t)val[r]) { found[r] = true; st[r] = 0; stop[r] = cand[r]; }
-                else { st[r] = 2; cand[r] = cand[r] + 1; }       // fingerprint collision: keep walking
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            if (st[r] == 2) {
-                uint64_t s = probe_slow(tab, val[r], fp[r], cand[r], &ent[r], &stop[r]);
-                found[r] = s != kNotFound;
-                if (found[r]) cand[r] = s;
-            }
-        }
-        if (COUNTERS) {
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                if (valid[r]) {
-                    uint64_t last = stop[r] < tab.limit ? stop[r] + 1 : tab.limit;
-                    ctr_slots += last - slot[r];
+            for (int q = 0; q < RPG; q++) {
+                if (AA) {
+                    uint32_t hi = la.H4[lane], lo = la.H4[lane + 4];
+                    uint32_t i = j * kAaWinPerBlock + lane;
+                    valid[q] = (hi != kInvalid) & (lo != kInvalid) & ((uint64_t)i + 8 < (uint64_t)L);
+                    val[q] = (uint64_t)hi * 160000ull + lo;
+                } else {
+                    const int r = g * RPG + q;                 // wave-uniform row: strand r/3, phase r%3
+                    const bool minus = r >= 3;
+                    const uint32_t pl = 3u * lane + (uint32_t)(minus ? r - 3 : r);
+                    const uint32_t *hc = minus ? ld.G : ld.H;
+                    uint32_t a = hc[pl], b = hc[pl + 12];
+                    valid[q] = (a != kInvalid) & (b != kInvalid);
+                    // '+': first four codons are the high half; '-': the codons over the higher bases are
+                    val[q] = minus ? (uint64_t)b * 160000ull + a : (uint64_t)a * 160000ull + b;
                 }
             }
-        } else {
-            (void)stop;
-        }
 
-        // ---- ordered compaction: ballot per row, one staging reservation per wave
-        uint32_t cnt[ROWS], rank[ROWS];
-        uint32_t total = 0;
+            // ---- probe: home slot, 16 tags per load, records touched only on a fingerprint match
+            uint64_t cand[RPG];     // slot under examination
+            uint32_t fp[RPG];
+            Tags16 tg[RPG];
+            uint64_t home[COUNTERS ? RPG : 1];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            unsigned long long m = __ballot(found[r]);
-            cnt[r] = (uint32_t)__popcll(m);
-            // '+' rows ascend with the lane, '-' rows descend: rank so that staging order == position order
-            unsigned long long below = m & ((1ull << lane) - 1ull);
-            unsigned long long above = lane == 63 ? 0ull : (m >> (lane + 1));
-            rank[r] = (!AA && r >= 3) ? (uint32_t)__popcll(above) : (uint32_t)__popcll(below);
-            total += cnt[r];
-        }
-        unsigned long long base = 0;
-        if (lane == 0) {
+            for (int q = 0; q < RPG; q++) {
+                cand[q] = home_slot(val[q], tab);
+                fp[q] = tag_of(val[q]);
+                if (COUNTERS) { home[q] = cand[q]; if (valid[q]) ctr_valid++; }   // query k-mers (KGJ:913-920)
+                valid[q] = valid[q] && cand[q] < tab.limit;     // beyond the stream: EOF, not found, nothing inspected
+                if (valid[q]) tg[q] = load_tags(tab.tags + cand[q]);
+            }
+            // state per row: resolved, candidate at cand[q] (bit in st1), or keep walking from cand[q] (bit in pend)
+            uint32_t st1 = 0, pend = 0;
+            uint64_t stop[COUNTERS ? RPG : 1];
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) a.counts[vrow[r]] = cnt[r];
-            if (total) base = atomicAdd(a.cursor, (unsigned long long)total);
-            a.block_stage_base[it] = (uint32_t)base;
-        }
-        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
-               (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base);
-        if (total && base + total <= a.stage_cap) {
-            uint32_t rowbase = 0;
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                if (found[r]) {
-                    kg_hit h;
-                    h.container = cont[r];
-                    h.from0InProt = pos[r];
-                    h.oI = ent[r].oI; h.avgOffFromEnd = ent[r].avg; h.fI = ent[r].fI; h.functionWt = ent[r].wt;
-                    a.stage[base + rowbase + rank[r]] = h;
+            for (int q = 0; q < RPG; q++) {
+                if (COUNTERS) stop[q] = cand[q];
+                if (valid[q]) {
+                    bool emp;
+                    int i = first_stop(tg[q], fp[q], &emp);
+                    if (i == 16) { pend |= 1u << q; cand[q] += 16; }
+                    else {
+                        cand[q] += (uint64_t)i;
+                        if (COUNTERS) stop[q] = cand[q];
+                        if (!emp) st1 |= 1u << q;
+                    }
                 }
-                rowbase += cnt[r];
+            }
+            Payload ent[RPG];       // the 16 payload bytes of the matching record
+            uint32_t foundm = 0;
+            {
+                Entry full[RPG];
+#pragma unroll
+                for (int q = 0; q < RPG; q++)
+                    if (st1 & (1u << q)) full[q] = load_entry(tab, cand[q]);
+#pragma unroll
+                for (int q = 0; q < RPG; q++) {
+                    if (st1 & (1u << q)) {
+                        if (full[q].key == (int64_t)val[q]) foundm |= 1u << q;
+                        else { pend |= 1u << q; cand[q] += 1; }       // fingerprint collision: keep walking
+                    }
+                    ent[q].oI = full[q].oI; ent[q].avg = full[q].avg; ent[q].fI = full[q].fI; ent[q].wt = full[q].wt;
+                }
+            }
+            // rows that need the generic walk (KGJ:944-1034 semantics: forward until the k-mer, an empty slot or
+            // the end of the stream; never wrap).  Rare; one shared copy of the walk, rows picked by register muxes.
+            while (__ballot(pend != 0)) {
+                if (pend) {
+                    const int r = __builtin_ctz(pend);
+                    uint64_t v = val[0], s = cand[0];
+                    uint32_t f = fp[0];
+#pragma unroll
+                    for (int q = 1; q < RPG; q++)
+                        if (r == q) { v = val[q]; s = cand[q]; f = fp[q]; }
+                    bool done = false, hit = false;
+                    Entry e;
+                    e.key = 0; e.oI = e.avg = e.fI = 0; e.wt = 0.f;
+                    if (s >= tab.limit) { done = true; s = tab.limit; }
+                    else {
+                        Tags16 x = load_tags(tab.tags + s);
+                        bool emp;
+                        int i = first_stop(x, f, &emp);
+                        if (i == 16) s += 16;
+                        else if (emp) { done = true; s += (uint64_t)i; }
+                        else {
+                            s += (uint64_t)i;
+                            e = load_entry(tab, s);
+                            if (e.key == (int64_t)v) done = hit = true;
+                            else s += 1;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < RPG; q++) {
+                        if (r == q) {
+                            cand[q] = s;
+                            if (done) {
+                                if (COUNTERS) stop[q] = s;
+                                if (hit) { ent[q].oI = e.oI; ent[q].avg = e.avg; ent[q].fI = e.fI; ent[q].wt = e.wt; foundm |= 1u << q; }
+                            }
+                        }
+                    }
+                    if (done) pend &= pend - 1;
+                }
+            }
+            if (COUNTERS) {
+#pragma unroll
+                for (int q = 0; q < RPG; q++) {
+                    if (valid[q]) {
+                        uint64_t last = stop[q] < tab.limit ? stop[q] + 1 : tab.limit;
+                        ctr_slots += last - home[q];
+                    }
+                }
+            }
+
+            // ---- ordered compaction: ballot per row, staging records handed out from the wave's reservation
+            uint32_t cnt[RPG], rank[RPG];
+            uint32_t total = 0;
+#pragma unroll
+            for (int q = 0; q < RPG; q++) {
+                const int r = g * RPG + q;
+                unsigned long long m = __ballot((foundm >> q) & 1u);
+                cnt[q] = (uint32_t)__popcll(m);
+                // '+' rows ascend with the lane, '-' rows descend: rank so that staging order == position order
+                unsigned long long below = m & ((1ull << lane) - 1ull);
+                unsigned long long above = lane == 63 ? 0ull : (m >> (lane + 1));
+                rank[q] = (!AA && r >= 3) ? (uint32_t)__popcll(above) : (uint32_t)__popcll(below);
+                total += cnt[q];
+                // hits per (container, block) in container-major order: rows of one container are contiguous
+                uint32_t vrow;
+                if (AA) vrow = it;
+                else if (r < 3) vrow = vbase + (uint32_t)r * nk + j;
+                else vrow = vbase + (3u + (L - (uint32_t)(r - 3)) % 3u) * nk + (nk - 1u - j);
+                if (lane == 0) counts[vrow] = cnt[q];
+            }
+            if (total > res_end - res_at) {                      // uniform: take a new chunk
+                unsigned long long chunk = total > stage_chunk ? total : stage_chunk;
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(cursor, chunk);
+                b = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                    (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)b);
+                res_at = b; res_end = b + chunk;
+            }
+            const unsigned long long base = res_at;
+            res_at += total;
+            if (lane == 0) block_stage_base[(uint64_t)it * NG + g] = (uint32_t)base;
+            if (total && base + total <= stage_cap) {
+                uint32_t rowbase = 0;
+#pragma unroll
+                for (int q = 0; q < RPG; q++) {
+                    const int r = g * RPG + q;
+                    if ((foundm >> q) & 1u) {
+                        kg_hit h;
+                        if (AA) {
+                            h.container = bd.seq;
+                            h.from0InProt = (int32_t)(j * kAaWinPerBlock + lane);
+                        } else if (r < 3) {
+                            // '+' strand: frame r (block start is a multiple of 3), residue index 64j + lane
+                            h.container = bd.seq * 6u + (uint32_t)r;
+                            h.from0InProt = (int32_t)(j * 64u + lane);
+                        } else {
+                            // '-' strand: the window over forward bases p..p+23 starts at reverse-complement base
+                            // b' = L-24-p, i.e. frame b'%3, residue b'/3 (KGJ:1068-1072).  24 % 3 == 0 and the
+                            // block start is a multiple of 3, so the frame depends on the row only.
+                            const uint32_t f = (uint32_t)(r - 3);
+                            h.container = bd.seq * 6u + 3u + (L - f) % 3u;
+                            h.from0InProt = (int32_t)((L - 24u - f - j * kDnaPosPerBlock) / 3u) - (int32_t)lane;
+                        }
+                        h.oI = ent[q].oI; h.avgOffFromEnd = ent[q].avg; h.fI = ent[q].fI; h.functionWt = ent[q].wt;
+                        stage[base + rowbase + rank[q]] = h;
+                    }
+                    rowbase += cnt[q];
+                }
             }
         }
+        wave_sync();   // LDS is reused by the next block
     }
 
     if (COUNTERS) {
@@ -430,8 +466,8 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(ScanArgs a)
             ctr_slots += __shfl_down(ctr_slots, off);
         }
         if (lane == 0) {
-            atomicAdd(&a.ctr[0], ctr_valid);
-            atomicAdd(&a.ctr[1], ctr_slots);
+            atomicAdd(&ctr[0], ctr_valid);
+            atomicAdd(&ctr[1], ctr_slots);
         }
     }
 }
@@ -557,19 +593,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_final_kernel(const uint32_t
 // Ordered placement: staging (block-granular, arbitrary block order) -> hits[] ordered by
 // (container, from0InProt).  One wave per block; rows in the order the scan kernel staged them.
 template <bool AA>
-__global__ __launch_bounds__(kWave *kWavesPerWG) void place_kernel(const BlockDesc *blocks, uint32_t n_blocks,
-                                                                  const uint32_t *counts, const uint32_t *offs,
-                                                                  const uint32_t *block_stage_base,
-                                                                  const kg_hit *stage, kg_hit *hits)
+__global__ __launch_bounds__(kWave *kWavesPerWG) void place_kernel(const BlockDesc *__restrict__ blocks, uint32_t n_blocks,
+                                                                  const uint32_t *__restrict__ counts,
+                                                                  const uint32_t *__restrict__ offs,
+                                                                  const uint32_t *__restrict__ block_stage_base, uint32_t rpg,
+                                                                  const kg_hit *__restrict__ stage, kg_hit *__restrict__ hits)
 {
     constexpr int ROWS = AA ? 1 : 6;
     const int lane = threadIdx.x & 63;
     const uint32_t it = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerWG + (threadIdx.x >> 6));
     if (it >= n_blocks) return;
     const BlockDesc bd = blocks[it];
-    uint32_t src = block_stage_base[it];
+    const uint32_t ng = (uint32_t)ROWS / rpg;
+    uint32_t src = 0;
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
+        if ((uint32_t)r % rpg == 0) src = block_stage_base[(uint64_t)it * ng + (uint32_t)r / rpg];
         uint32_t vrow;
         if (AA) vrow = it;
         else if (r < 3) vrow = 6u * bd.ibase + (uint32_t)r * bd.nk + bd.j;
@@ -594,152 +633,6 @@ __global__ void container_starts_kernel(const uint32_t *ibase, uint32_t n_seqs, 
     uint32_t nk = ibase[k + 1] - ibase[k];
     uint64_t row = (uint64_t)PER * ibase[k] + (uint64_t)cc * nk;
     chs[c] = row < n_rows ? (int64_t)offs[row] : (int64_t)*total;
-}
-
-// ---------------------------------------------------------------------------------------
-// Aggregation.  gatherHits (KGJ:457-514) + processSetOfHits (KGJ:385-455) as a state machine over
-// the container's position-ordered hits.  The reference's "hits" list is always the accepted
-// records inside one index range [lo, last] of that array (it is only ever cleared or cut down to
-// its last two members), so the list is represented by (lo, last, prev, cnt) plus one "accepted"
-// byte per hit (order constraint, KGJ:490-494, and the 39 998 cap, KGJ:496, reject records).
-struct AggParams { int32_t min_hits, min_weighted_hits, max_gap, order_constraint; };
-
-struct CallSpan { uint32_t lo, last_hit; };   // global hit indices of the called set's first record and last voter
-
-template <bool EMIT>
-struct CallSink {
-    kg_call *calls; CallSpan *spans; uint64_t at; uint32_t n;
-};
-
-template <bool EMIT>
-__device__ void gather_container(const kg_hit *h, int64_t begin, int64_t end, const AggParams p, uint8_t *acc,
-                                 uint32_t container, CallSink<EMIT> &sink)
-{
-    int64_t lo = begin, last = begin, prev = begin;
-    int32_t cnt = 0;
-    int32_t currentFI = 0;
-
-    auto process = [&]() {
-        // KGJ:387-396
-        int32_t fICount = 0;
-        float weighted = 0.f;
-        int64_t lastHit = lo;
-        for (int64_t k = lo; k <= last; k++) {
-            if (acc[k] && h[k].fI == currentFI) {
-                lastHit = k;
-                fICount++;
-                weighted += h[k].functionWt;      // float32, list order
-            }
-        }
-        if (fICount >= p.min_hits && weighted >= (float)p.min_weighted_hits) {   // KGJ:397
-            if (EMIT) {
-                kg_call c;
-                c.container = container;
-                c.start = h[lo].from0InProt;
-                c.end = h[lastHit].from0InProt + (KG_K - 1);
-                c.count = fICount; c.fI = currentFI; c.weightedHits = weighted;
-                sink.calls[sink.at + sink.n] = c;
-                CallSpan s; s.lo = (uint32_t)lo; s.last_hit = (uint32_t)lastHit;
-                sink.spans[sink.at + sink.n] = s;
-            }
-            sink.n++;
-        }
-        // KGJ:441-453: keep the last two records if they start a new function, else clear
-        if (h[prev].fI != currentFI && h[prev].fI == h[last].fI) {
-            currentFI = h[last].fI;
-            lo = prev;
-            cnt = 2;
-        } else {
-            cnt = 0;
-        }
-    };
-
-    for (int64_t i = begin; i < end; i++) {
-        const int32_t ppos = h[i].from0InProt, fI = h[i].fI, avg = h[i].avgOffFromEnd;
-        if (cnt > 0 && (int32_t)((uint32_t)h[last].from0InProt + (uint32_t)p.max_gap) < ppos) {   // KGJ:477-484
-            if (cnt >= p.min_hits) process(); else cnt = 0;
-        }
-        if (cnt == 0) currentFI = fI;                                                             // KGJ:486-488
-        bool ok = !p.order_constraint || cnt == 0;
-        if (!ok) {                                                                                // KGJ:490-494
-            int32_t d = (int32_t)((uint32_t)(ppos - h[last].from0InProt) - (uint32_t)(h[last].avgOffFromEnd - avg));
-            int32_t ad = d < 0 ? (int32_t)(0u - (uint32_t)d) : d;      // Math.abs(int)
-            ok = fI == h[last].fI && ad <= 20;
-        }
-        bool appended = false;
-        if (ok) {
-            if (cnt < KG_MAX_HITS_PER_SEQ - 2) {                                                  // KGJ:496-497
-                if (cnt == 0) { lo = i; prev = i; } else { prev = last; }
-                last = i;
-                cnt++;
-                appended = true;
-            }
-        }
-        acc[i] = appended ? 1 : 0;
-        if (ok && cnt > 1 && currentFI != fI && h[prev].fI == h[last].fI) process();             // KGJ:503-508
-    }
-    if (cnt >= p.min_hits) process();                                                            // KGJ:511-513
-}
-
-// one lane per container
-template <bool EMIT>
-__global__ void calls_kernel(const kg_hit *hits, const int64_t *chs, uint64_t n_cont, AggParams p, uint8_t *acc,
-                             uint32_t *call_cnt, const uint32_t *call_off, kg_call *calls, CallSpan *spans)
-{
-    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cont) return;
-    CallSink<EMIT> sink;
-    sink.calls = calls; sink.spans = spans; sink.n = 0;
-    sink.at = EMIT ? call_off[c] : 0;
-    gather_container<EMIT>(hits, chs[c], chs[c + 1], p, acc, (uint32_t)c, sink);
-    if (!EMIT) call_cnt[c] = sink.n;
-}
-
-// ccs[c] = call_off[c] widened, plus sentinel
-__global__ void call_starts_kernel(const uint32_t *call_off, uint64_t n_cont, const uint64_t *total, int64_t *ccs)
-{
-    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > n_cont) return;
-    ccs[c] = c == n_cont ? (int64_t)*total : (int64_t)call_off[c];
-}
-
-// OTU vote (KGJ:413-439), one lane per sequence: replay the voters of every CALL of the sequence
-// in emission order against the 5-entry buffer that persists across the sequence's containers
-// (KGJ:528, 540).
-__global__ void otu_kernel(const kg_hit *hits, const uint8_t *acc, const kg_call *calls, const CallSpan *spans,
-                           const int64_t *ccs, uint32_t n_seqs, uint32_t per, kg_otu *otu)
-{
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seqs) return;
-    int32_t n = 0;
-    int32_t cnt[KG_OI_BUFSZ] = {0, 0, 0, 0, 0}, oi[KG_OI_BUFSZ] = {0, 0, 0, 0, 0};
-    int64_t c0 = ccs[(uint64_t)s * per], c1 = ccs[(uint64_t)(s + 1) * per];
-    for (int64_t c = c0; c < c1; c++) {
-        const int32_t fI = calls[c].fI;
-        const CallSpan sp = spans[c];
-        for (uint32_t k = sp.lo; k <= sp.last_hit; k++) {
-            if (!acc[k] || hits[k].fI != fI) continue;
-            const int32_t o = hits[k].oI;
-            int j = 0;
-            while (j < n && oi[j] != o) j++;
-            if (j == n) {
-                if (n == KG_OI_BUFSZ) j--; else n++;
-                oi[j] = o; cnt[j] = 1;
-            } else {
-                cnt[j]++;
-            }
-            while (j > 0 && cnt[j - 1] <= cnt[j]) {
-                int32_t tc = cnt[j - 1], to = oi[j - 1];
-                cnt[j - 1] = cnt[j]; oi[j - 1] = oi[j];
-                cnt[j] = tc; oi[j] = to;
-                j--;
-            }
-        }
-    }
-    kg_otu r;
-    r.n = n;
-    for (int k = 0; k < KG_OI_BUFSZ; k++) { r.count[k] = k < n ? cnt[k] : 0; r.oI[k] = k < n ? oi[k] : 0; }
-    otu[s] = r;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -3,16 +3,20 @@
 // Replaces, for a batch of sequences, the reference's run() body between readFasta and the
 // report printers (KGJ:776-816): prepareQuery/addKmers, the query sort, lookup and
 // gatherHits/processSetOfHits.  Everything runs on one HIP stream owned by the table object;
-// scratch and results come from the stream-ordered pool (hipMallocAsync) so that repeated
+// scratch and results come from a per-table cache of device blocks (DevCache) so that repeated
 // scans reuse the same HBM.
 #include "kg_device.hpp"
+#include "kg_aggregate.hpp"
 
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -32,9 +36,59 @@ int fail(int code, const std::string &msg)
             return fail(KG_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
+// Device-memory cache of one table object.  Every scan ends with a stream synchronisation, and
+// blocks are handed back only when the stream is idle, so a freed block can be reused by the next
+// request without any ordering concern.  Keeps the working set of repeated scans resident in HBM
+// (no hipMalloc/hipFree in the steady state).
+struct DevCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_;
+    std::unordered_map<void *, size_t> live;
+
+    static size_t round_up(size_t b)
+    {
+        if (b < 256) return 256;
+        size_t g = b >= (8u << 20) ? (2u << 20) : 256;       // 2 MiB granules for large blocks
+        return (b + g - 1) / g * g;
+    }
+    hipError_t get(void **p, size_t bytes)
+    {
+        bytes = round_up(bytes);
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = free_.lower_bound(bytes);
+        if (it != free_.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
+            *p = it->second;
+            live[*p] = it->first;
+            free_.erase(it);
+            return hipSuccess;
+        }
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) {
+            // give cached blocks back to the driver and retry once
+            for (auto &kv : free_) (void)hipFree(kv.second);
+            free_.clear();
+            e = hipMalloc(p, bytes);
+            if (e != hipSuccess) return e;
+        }
+        live[*p] = bytes;
+        return hipSuccess;
+    }
+    void put(void *p)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_.emplace(it->second, p);
+        live.erase(it);
+    }
+    void release_all()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &kv : free_) (void)hipFree(kv.second);
+        for (auto &kv : live) (void)hipFree(kv.first);
+        free_.clear();
+        live.clear();
+    }
 };
 
 }  // namespace
@@ -51,6 +105,7 @@ struct kg_table {
     uint64_t occupied = 0;
     double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
     hipEvent_t ev[6] = {};
+    DevCache cache;
 };
 
 struct kg_result {
@@ -73,22 +128,34 @@ struct kg_result {
 
 namespace {
 
+uint32_t env_u32(const char *name, uint32_t dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    long x = strtol(v, nullptr, 10);
+    return x > 0 ? (uint32_t)x : dflt;
+}
+
 int dalloc(kg_table *t, void **p, size_t bytes)
 {
-    if (bytes == 0) bytes = 256;
-    HIP_TRY(hipMallocAsync(p, bytes, t->stream));
+    hipError_t e = t->cache.get(p, bytes);
+    if (e != hipSuccess) return fail(KG_ERR_NOMEM, std::string("device allocation failed: ") + hipGetErrorString(e));
     return KG_OK;
 }
 
+// Only call while the table's stream is idle (see DevCache).
 void dfree(kg_table *t, void *p)
 {
-    if (p) (void)hipFreeAsync(p, t->stream);
+    if (p) t->cache.put(p);
 }
 
 int table_finish(kg_table *t)
 {
     // tag array + occupancy count: one streaming pass over the records
     HIP_TRY(hipSetDevice(t->device));
+    // the records may have been produced on another stream (kg_table_from_device): the library's
+    // stream is non-blocking, so wait for everything the device has been given so far
+    HIP_TRY(hipDeviceSynchronize());
     unsigned __int128 one = 1;
     if (t->num_sigs == 1) t->magic = ~0ull;
     else t->magic = (uint64_t)((one << 64) / (unsigned __int128)(uint64_t)t->num_sigs);
@@ -123,12 +190,6 @@ int table_new(int device, kg_table **out)
     t->device = device;
     hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete t; return fail(KG_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-    // keep freed scratch in the pool: the next scan reuses it without going back to the driver
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-        uint64_t thr = UINT64_MAX;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-    }
     *out = t;
     return KG_OK;
 }
@@ -272,6 +333,7 @@ void kg_table_close(kg_table *t)
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     if (t->own_entries && t->d_entries) (void)hipFree(t->d_entries);
     if (t->d_tags) (void)hipFree(t->d_tags);
+    t->cache.release_all();
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -283,7 +345,7 @@ void kg_result_free(kg_result *r)
     if (!r) return;
     kg_table *t = r->tab;
     if (t) {
-        (void)hipSetDevice(t->device);
+        // a result is only handed out after its scan has synchronised the stream
         dfree(t, r->d_hits); dfree(t, r->d_chs); dfree(t, r->d_calls); dfree(t, r->d_ccs); dfree(t, r->d_otu);
     }
     delete r;
@@ -309,7 +371,12 @@ struct Scratch {
     kg_table *t;
     std::vector<void *> ptrs;
     explicit Scratch(kg_table *tt) : t(tt) {}
-    ~Scratch() { for (void *p : ptrs) dfree(t, p); }
+    ~Scratch()
+    {
+        (void)hipStreamSynchronize(t->stream);      // blocks go back to the cache only when the stream is idle
+        for (void *p : ptrs) dfree(t, p);
+    }
+    void adopt(void *p) { ptrs.push_back(p); }
     template <typename T> int get(T **p, size_t count)
     {
         void *v = nullptr;
@@ -354,7 +421,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         if (nblocks > 0x7FFFFFFFull / PER) return fail(KG_ERR_LIMIT, "batch too large: more than 2^31-1 window rows; split the batch");
     }
     ibase[(size_t)n_seqs] = (uint32_t)nblocks;
-    if (windows > 0xFFFFFFFFull) return fail(KG_ERR_LIMIT, "batch too large: more than 2^32-1 windows; split the batch");
+    if (windows > 0xFFFFFF00ull) return fail(KG_ERR_LIMIT, "batch too large: more than 2^32-256 windows; split the batch");
     const uint64_t n_rows = nblocks * PER;
     const uint64_t n_cont = (uint64_t)n_seqs * PER;
     st.n_seqs = n_seqs; st.n_containers = (int64_t)n_cont; st.n_blocks = (int64_t)nblocks;
@@ -375,7 +442,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
     if ((rc = sc.get(&d_blocks, nblocks))) return rc;
     if ((rc = sc.get(&d_counts, n_rows))) return rc;
     if ((rc = sc.get(&d_offs, n_rows))) return rc;
-    if ((rc = sc.get(&d_bsb, nblocks))) return rc;
+    if ((rc = sc.get(&d_bsb, nblocks * 6))) return rc;      // one staging base per (block, row group)
     uint64_t max_scan = n_rows > n_cont ? n_rows : n_cont;
     if ((rc = sc.get(&d_partial, (size_t)(max_scan / kg::kScanChunk + 2)))) return rc;
     if ((rc = sc.get(&d_totals, 8))) return rc;
@@ -391,35 +458,50 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
     }
 
     // ---- scan: encode + probe + staged compaction; re-run once if the staging area was too small ----
-    uint64_t stage_cap = (uint64_t)((double)windows * t->stage_ratio) + 4096;
-    if (stage_cap > windows) stage_cap = windows;
-    if (stage_cap == 0) stage_cap = 1;
+    // persistent grid: enough workgroups to fill 256 CUs, few enough that per-wave staging chunks stay small
+    const uint32_t scan_grid = env_u32("KG_SCAN_GRID", 256u * 8u);
+    const uint32_t stage_chunk = env_u32("KG_STAGE_CHUNK", 256u);
+    uint32_t rpg = AA ? 1u : env_u32("KG_SCAN_RPG", 3u);      // rows probed together per lane
+    if (rpg != 1 && rpg != 2 && rpg != 3 && rpg != 6) rpg = 3;
+    (void)0;
+    uint64_t stage_cap = (uint64_t)((double)windows * t->stage_ratio) + 4096 +
+                         (uint64_t)scan_grid * kg::kWavesPerWG * stage_chunk;
+    if (stage_cap > 0xFFFFFF00ull) stage_cap = 0xFFFFFF00ull;
     kg_hit *d_stage = nullptr;
     uint64_t n_hits = 0;
     st.scan_launches = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = dalloc(t, (void **)&d_stage, stage_cap * sizeof(kg_hit)))) return rc;
-        kg::ScanArgs a;
-        a.tab.entries = t->d_entries; a.tab.tags = t->d_tags; a.tab.limit = t->limit;
-        a.tab.num_sigs = (uint64_t)t->num_sigs; a.tab.magic = t->magic;
-        a.seq = d_seq; a.blocks = d_blocks; a.n_blocks = (uint32_t)nblocks;
-        a.counts = d_counts; a.block_stage_base = d_bsb; a.stage = d_stage;
-        a.cursor = (unsigned long long *)(d_totals + 1); a.stage_cap = stage_cap;
-        a.ctr = (unsigned long long *)(d_totals + 2);
+        unsigned long long *d_cursor = (unsigned long long *)(d_totals + 1);
+        unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
         HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
         HIP_TRY(hipEventRecord(t->ev[1], t->stream));
         if (nblocks) {
             uint64_t wgs = (nblocks + kg::kWavesPerWG - 1) / kg::kWavesPerWG;
-            uint32_t grid = (uint32_t)(wgs < 256ull * 64 ? wgs : 256ull * 64);   // persistent waves stride over the blocks
-            if (counters)
-                hipLaunchKernelGGL((kg::scan_kernel<AA, true>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, t->stream, a);
-            else
-                hipLaunchKernelGGL((kg::scan_kernel<AA, false>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, t->stream, a);
+            uint32_t grid = (uint32_t)(wgs < scan_grid ? wgs : scan_grid);      // persistent waves stride over the blocks
+#define KG_SCAN_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic, d_seq, d_blocks, (uint32_t)nblocks, \
+                     d_counts, d_bsb, d_stage, d_cursor, stage_cap, stage_chunk, d_ctr
+#define KG_SCAN_LAUNCH(C, R) hipLaunchKernelGGL((kg::scan_kernel<AA, C, R>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, \
+                                                t->stream, KG_SCAN_ARGS)
+            if (AA) {
+                if (counters) KG_SCAN_LAUNCH(true, 1); else KG_SCAN_LAUNCH(false, 1);
+            } else {
+                constexpr int R1 = AA ? 1 : 1, R2 = AA ? 1 : 2, R3 = AA ? 1 : 3, R6 = AA ? 1 : 6;
+                if (counters) {
+                    if (rpg == 1) KG_SCAN_LAUNCH(true, R1); else if (rpg == 2) KG_SCAN_LAUNCH(true, R2);
+                    else if (rpg == 3) KG_SCAN_LAUNCH(true, R3); else KG_SCAN_LAUNCH(true, R6);
+                } else {
+                    if (rpg == 1) KG_SCAN_LAUNCH(false, R1); else if (rpg == 2) KG_SCAN_LAUNCH(false, R2);
+                    else if (rpg == 3) KG_SCAN_LAUNCH(false, R3); else KG_SCAN_LAUNCH(false, R6);
+                }
+            }
+#undef KG_SCAN_LAUNCH
+#undef KG_SCAN_ARGS
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(t->ev[2], t->stream));
         st.scan_launches++;
-        if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) { dfree(t, d_stage); return rc; }
+        if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) { sc.adopt(d_stage); return rc; }
         uint64_t h_tot[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 32, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
@@ -433,22 +515,22 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         stage_cap = h_tot[1];
     }
     if (windows) {
-        double ratio = (double)n_hits / (double)windows * 1.25 + 1e-3;
+        double ratio = (double)n_hits / (double)windows * 1.1 + 1e-3;
         if (ratio > t->stage_ratio) t->stage_ratio = ratio > 1.0 ? 1.0 : ratio;
     }
     st.n_hits = (int64_t)n_hits;
 
     // ---- ordered placement ----
-    if ((rc = dalloc(t, (void **)&res->d_hits, n_hits * sizeof(kg_hit)))) { dfree(t, d_stage); return rc; }
+    sc.adopt(d_stage);
+    if ((rc = dalloc(t, (void **)&res->d_hits, n_hits * sizeof(kg_hit)))) return rc;
     if (nblocks) {
         uint32_t grid = (uint32_t)((nblocks + kg::kWavesPerWG - 1) / kg::kWavesPerWG);
         hipLaunchKernelGGL((kg::place_kernel<AA>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, t->stream, d_blocks,
-                           (uint32_t)nblocks, d_counts, d_offs, d_bsb, d_stage, res->d_hits);
+                           (uint32_t)nblocks, d_counts, d_offs, d_bsb, rpg, d_stage, res->d_hits);
     }
     hipLaunchKernelGGL((kg::container_starts_kernel<AA>), dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream,
                        d_ibase, (uint32_t)n_seqs, d_offs, n_rows, d_totals, res->d_chs);
     HIP_TRY(hipGetLastError());
-    dfree(t, d_stage);
     HIP_TRY(hipEventRecord(t->ev[3], t->stream));
 
     // ---- aggregation: CALL records and OTU votes ----
@@ -463,10 +545,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         if ((rc = sc.get(&d_coff, n_cont))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_ccs, (n_cont + 1) * 8))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_otu, (size_t)(n_seqs ? n_seqs : 1) * sizeof(kg_otu)))) return rc;
-        uint32_t cgrid = (uint32_t)((n_cont + 63) / 64);
+        uint32_t cgrid = (uint32_t)((n_cont + 3) / 4);           // one wave per container
         if (n_cont) {
-            hipLaunchKernelGGL((kg::calls_kernel<false>), dim3(cgrid), dim3(64), 0, t->stream, res->d_hits, res->d_chs, n_cont,
-                               ap, d_acc, d_ccnt, (const uint32_t *)nullptr, (kg_call *)nullptr, (kg::CallSpan *)nullptr);
+            hipLaunchKernelGGL((kg::calls_wave_kernel<false>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
+                               (uint32_t)n_cont, ap, d_acc, d_ccnt, (const uint32_t *)nullptr, (kg_call *)nullptr,
+                               (kg::CallSpan *)nullptr);
             HIP_TRY(hipGetLastError());
         }
         if ((rc = prefix_sum(t, d_ccnt, n_cont, d_coff, d_partial, d_totals + 4))) return rc;
@@ -476,15 +559,15 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         n_calls = n_cont ? h_calls : 0;
         if ((rc = dalloc(t, (void **)&res->d_calls, n_calls * sizeof(kg_call)))) return rc;
         if ((rc = sc.get(&d_spans, n_calls))) return rc;
-        if (n_cont) {
-            hipLaunchKernelGGL((kg::calls_kernel<true>), dim3(cgrid), dim3(64), 0, t->stream, res->d_hits, res->d_chs, n_cont,
-                               ap, d_acc, (uint32_t *)nullptr, d_coff, res->d_calls, d_spans);
+        if (n_cont && n_calls) {
+            hipLaunchKernelGGL((kg::calls_wave_kernel<true>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
+                               (uint32_t)n_cont, ap, d_acc, d_ccnt, d_coff, res->d_calls, d_spans);
         }
         hipLaunchKernelGGL(kg::call_starts_kernel, dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream, d_coff,
                            n_cont, d_totals + 4, res->d_ccs);
         if (n_seqs) {
-            hipLaunchKernelGGL(kg::otu_kernel, dim3((uint32_t)((n_seqs + 63) / 64)), dim3(64), 0, t->stream, res->d_hits, d_acc,
-                               res->d_calls, d_spans, res->d_ccs, (uint32_t)n_seqs, PER, res->d_otu);
+            hipLaunchKernelGGL(kg::otu_wave_kernel, dim3((uint32_t)((n_seqs + 3) / 4)), dim3(256), 0, t->stream, res->d_hits,
+                               d_acc, res->d_calls, d_spans, res->d_ccs, (uint32_t)n_seqs, PER, res->d_otu);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -527,10 +610,10 @@ int scan_entry(kg_table *t, const kg_params *p, const uint8_t *seq, bool on_devi
         const uint8_t *s = on_device ? seq : d_seq;
         rc = p->aa ? scan_impl<true>(t, p, s, offsets, n_seqs, r) : scan_impl<false>(t, p, s, offsets, n_seqs, r);
     }
+    (void)hipStreamSynchronize(t->stream);
     if (d_seq) dfree(t, d_seq);
     if (rc != KG_OK) {
         std::string keep = g_err;
-        (void)hipStreamSynchronize(t->stream);
         kg_result_free(r);
         g_err = keep;
         return rc;
@@ -604,5 +687,6 @@ const kg_otu *kg_result_otu(kg_result *r)
 }
 const void *kg_result_device_hits(const kg_result *r) { return r ? r->d_hits : nullptr; }
 const void *kg_result_device_calls(const kg_result *r) { return r ? r->d_calls : nullptr; }
+const void *kg_result_device_otu(const kg_result *r) { return r ? r->d_otu : nullptr; }
 
 }  // extern "C"

@@ -73,6 +73,9 @@ class ScanResult:
     def device_calls_ptr(self) -> int:
         return self._need().kg_result_device_calls(self._h) or 0
 
+    def device_otu_ptr(self) -> int:
+        return self._need().kg_result_device_otu(self._h) or 0
+
     def close(self) -> None:
         if self._h:
             N.load().kg_result_free(self._h)

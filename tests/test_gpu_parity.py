@@ -180,3 +180,69 @@ def test_determinism_and_device_input(hp, oracle):
             assert_same_records(r1, ora, "mix host input")
             assert_same_records(r2, ora, "mix device input")
             assert r1.hits().tobytes() == r2.hits().tobytes()
+
+
+def _single_function_protein(keys, rec, n_kmers, fn_pick=0, alt_every=0):
+    """A protein built from signature 8-mers that all carry one function index (long list, no pair rule)."""
+    from kmergutsjava_amd import synth
+    r = rec.numpy()
+    occupied = r[:, 1] < 5                       # key high word < 5  <=> whichKmer < 5 * 2^32 (occupied)
+    fn = r[occupied, 4]
+    kk = (r[occupied, 1].astype(np.int64) << 32) | (r[occupied, 0].astype(np.int64) & 0xFFFFFFFF)
+    vals, counts = np.unique(fn, return_counts=True)
+    f = vals[np.argsort(-counts)[fn_pick]]
+    pool = kk[fn == f]
+    other = kk[fn != f]
+    parts = []
+    for i in range(n_kmers):
+        if alt_every and i % alt_every == alt_every - 1:
+            parts.append(synth.decode_kmer(int(other[i % len(other)])))
+        else:
+            parts.append(synth.decode_kmer(int(pool[i % len(pool)])))
+    return "".join(parts)
+
+
+@pytest.mark.parametrize("oc", [False, True])
+def test_hit_cap_39998(hp, oracle, oc):
+    """More than MAX_HITS_PER_SEQ - 2 records in one list (KGJ:496): records beyond the cap are dropped,
+    the pair rule keeps being evaluated on the frozen list, and the list later restarts far behind."""
+    from kmergutsjava_amd import synth
+    seq, off, rec, keys = synth.high_density_config(2, 50, 20011, 6000, dna=False)
+    img = _img(rec)
+    prot = (_single_function_protein(keys, rec, 41000) +            # > 39 998 same-function hits, 8 apart
+            _single_function_protein(keys, rec, 300, fn_pick=1) +    # a different function right behind
+            _single_function_protein(keys, rec, 3000, alt_every=5))
+    short = _single_function_protein(keys, rec, 500, fn_pick=2)
+    sb = (prot + short).encode()
+    off = np.array([0, len(prot), len(prot) + len(short)], dtype=np.int64)
+    ora = oracle.run(img, sb, off, aa=True, lookup_mode=1, order_constraint=oc, max_gap=10)
+    assert np.diff(ora["container_hit_start"]).max() > 40000
+    with hp.SignatureTable.from_bytes(img) as tab:
+        with tab.scan(sb, off, hp.Params(aa=True, order_constraint=oc, max_gap=10)) as r:
+            assert_same_records(r, ora, "cap oc=%s" % oc)
+    if not oc:
+        assert ora["calls"]["count"].max() == 39998
+
+
+def test_midsize_persistent_waves(hp, oracle):
+    """Enough blocks that every persistent wave walks several of them (grid-stride loop, staging
+    chunks handed out across blocks), checked record for record against the oracle."""
+    import os
+    from kmergutsjava_amd import synth
+    rec, placed, keys = synth.random_table(3_000_017, 0.5, 41)
+    img = _img(rec)
+    seq, off = synth.dna_mix_config(12_000_000)
+    sb = plant(seq.numpy().tobytes(), off, keys.tolist(), every=97)
+    ora = oracle.run(img, sb, off, lookup_mode=1)
+    assert len(ora["hits"]) > 100000
+    with hp.SignatureTable.from_bytes(img) as tab:
+        for grid, rpg, chunk in ((64, 3, 16), (256, 6, 512), (2048, 1, 1), (2048, 2, 64)):
+            os.environ["KG_SCAN_GRID"] = str(grid); os.environ["KG_SCAN_RPG"] = str(rpg)
+            os.environ["KG_STAGE_CHUNK"] = str(chunk)
+            try:
+                with tab.scan(sb, off, hp.Params(counters=True)) as r:
+                    assert_same_records(r, ora, "midsize grid=%d rpg=%d chunk=%d" % (grid, rpg, chunk))
+                    assert r.stats["slots_inspected"] == ora["slots_inspected"]
+            finally:
+                for k in ("KG_SCAN_GRID", "KG_SCAN_RPG", "KG_STAGE_CHUNK"):
+                    os.environ.pop(k, None)

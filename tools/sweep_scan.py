@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Sweep the scan kernel's tunables (rows per group, staging chunk, persistent grid) at full size.
+Writes one JSON line per variant to stdout.  Tuning aid, not part of the product path."""
+import itertools, json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kmergutsjava_amd import hotpath, synth
+
+num_sigs = int(os.environ.get("SW_NUM_SIGS", "1400303159"))
+total_bp = int(os.environ.get("SW_TOTAL_BP", "1000000000"))
+dev = torch.device("cuda", 0)
+rec, placed, keys = synth.random_table(num_sigs, 0.5, 202, dev); del keys
+torch.cuda.synchronize()
+tab = hotpath.SignatureTable.from_device_ptr(rec.data_ptr(), num_sigs, 0, keepalive=rec)
+lens = synth.contig_mix_lengths(total_bp, 301); off = synth.offsets_of(lens)
+seq = synth.random_dna(int(off[-1]), 302, dev)
+torch.cuda.synchronize()
+variants = []
+for rpg in (1, 2, 3, 6):
+    variants.append(dict(KG_SCAN_RPG=rpg, KG_STAGE_CHUNK=512, KG_SCAN_GRID=2048))
+for chunk in (1, 64):
+    variants.append(dict(KG_SCAN_RPG=3, KG_STAGE_CHUNK=chunk, KG_SCAN_GRID=2048))
+for grid in (1024, 4096, 16384):
+    variants.append(dict(KG_SCAN_RPG=3, KG_STAGE_CHUNK=512, KG_SCAN_GRID=grid))
+for rpg, grid in ((2, 4096), (1, 4096), (2, 1024)):
+    variants.append(dict(KG_SCAN_RPG=rpg, KG_STAGE_CHUNK=512, KG_SCAN_GRID=grid))
+ref = None
+for v in variants:
+    for k, x in v.items():
+        os.environ[k] = str(x)
+    best = None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        with tab.scan(None, off, hotpath.Params(), device_ptr=seq.data_ptr()) as r:
+            st = r.stats
+            wall = (time.perf_counter() - t0) * 1e3
+            if rep == 2:
+                sig = (st["n_hits"], st["n_calls"])
+        if best is None or st["ms_scan"] < best["ms_scan"]:
+            best = dict(st, wall_ms=wall)
+    if ref is None:
+        ref = sig
+    assert sig == ref, (sig, ref)
+    print(json.dumps(dict(v, ms_scan=best["ms_scan"], ms_order=best["ms_order"], ms_aggregate=best["ms_aggregate"],
+                          ms_total=best["ms_total"], wall_ms=best["wall_ms"], launches=best["scan_launches"],
+                          n_hits=best["n_hits"])), flush=True)
