@@ -6,3 +6,5 @@ importing the package does not load it, using it does, and a missing library is 
 there is no CPU fallback.
 """
 __version__ = "0.1.0"
+
+from .kmer_guts_java import KmerGutsJava  # noqa: E402,F401  (imports no native code until used)

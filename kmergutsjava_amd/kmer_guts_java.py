@@ -1,0 +1,410 @@
+"""Host-side mirror of the reference's public interface for the hot path.
+
+    from kmergutsjava_amd import KmerGutsJava
+    KmerGutsJava.main(["-D", data_dir, "-q", "contigs.fna", "-o", "out.txt"])      # KGJ:560-654
+    KmerGutsJava().run(data_dir, fasta_path_or_None, writer, stdout)               # KGJ:742-820
+    KmerGutsJava().status()                                                        # KmerGutsJavaServer.java:33-45
+
+("KGJ:n" = reference lib/src/kmergutsjava/KmerGutsJava.java line n.)  Same flags, same data
+directory layout (kmer.table.mem_map[.gz], function.index[.gz]; KGJ:749-759), same FASTA rules
+(KGJ:1132-1192), same report text (KGJ:398-404, 518-548).  Everything between readFasta and the
+report printers runs on the GPU through the C ABI (hotpath.py -> libkmerguts_hip.so); this module
+only parses text and prints records.  There is no CPU fallback: without the library or without a
+GPU, run() raises.
+
+Known, documented deviations from the reference's behaviour:
+  * the progress lines "Processed: NN%, time=..." of the table stream (KGJ:1019-1025) are not
+    printed: the table is not streamed;
+  * -d prints the info lines but not the HIT / after-hit / after-call debug stream;
+  * -t / -l: the reference's switch falls through to "Unknown parameter" for both (KGJ:605-611);
+    this mirror does the same (message + usage, then carries on, KGJ:616-647);
+  * input beyond 20 M k-mers: the reference silently drops queries in its external merge
+    (KGJ:705-709); here nothing is dropped.
+"""
+from __future__ import annotations
+
+import gzip
+import io
+import os
+import sys
+import time
+from decimal import Decimal, ROUND_HALF_UP
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .hotpath import Params, SignatureTable
+
+_WS = " \t\n\x0b\x0c\r\x1c\x1d\x1e\x1f"      # what String.trim() strips is every char <= ' ' ; see _trim
+
+
+def _trim(s: str) -> str:
+    a, b = 0, len(s)
+    while a < b and s[a] <= " ":
+        a += 1
+    while b > a and s[b - 1] <= " ":
+        b -= 1
+    return s[a:b]
+
+
+def _read_lines(text: str) -> List[str]:
+    """BufferedReader.readLine(): \\n, \\r or \\r\\n end a line; no empty line after a final terminator."""
+    if not text:
+        return []
+    lines = text.replace("\r\n", "\n").replace("\r", "\n").split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    return lines
+
+
+def _parse_int(x: Optional[str]) -> int:
+    """Integer.parseInt with the reference's failure text."""
+    try:
+        if x is None:
+            raise ValueError
+        return int(x, 10)
+    except ValueError:
+        raise ValueError('For input string: "%s"' % x if x is not None else "null")
+
+
+def read_fasta(text: str, callback: Callable[[str, str, str], None]) -> None:
+    """readFasta (KGJ:1132-1192): id = first token after '>' (split on space / tab), sequence lines
+    concatenated untrimmed, blank lines before the sequence skipped, malformed input raises."""
+    lines = _read_lines(text)
+    n = len(lines)
+    i = 0
+    pending: Optional[str] = None          # str1 carried over from the previous record
+    have_pending = False
+    while True:
+        name = None
+        descr = ""
+        if not have_pending:
+            pending = lines[i] if i < n else None
+            i += 1
+        have_pending = False
+        while pending is not None:
+            t = _trim(pending)
+            if len(t) > 1:
+                if t[0] == ">" and len(_trim(t[1:])) > 0:
+                    toks = [x for x in t[1:].replace("\t", " ").split(" ") if x]
+                    name, descr = toks[0], " ".join(toks[1:])
+                    break
+                raise ValueError("Wrong caption line: " + t)
+            pending = lines[i] if i < n else None
+            i += 1
+        if name is None:
+            return
+        while True:
+            pending = lines[i] if i < n else None
+            i += 1
+            if pending is None or _trim(pending).startswith(">"):
+                raise ValueError("No sequence for caption: " + name)
+            if len(_trim(pending)) > 0:
+                break
+        parts = []
+        while True:
+            parts.append(pending)
+            pending = lines[i] if i < n else None
+            i += 1
+            if pending is None or _trim(pending).startswith(">"):
+                break
+        have_pending = True
+        seq = "".join(parts)
+        if not seq:
+            raise ValueError("No sequence for caption: " + name)
+        callback(name, seq, descr)
+
+
+def load_indexed_array(text: str) -> List[str]:
+    """loadIndexedArray (KGJ:345-369): '<i>\\t<value>' lines, dense and in order."""
+    out = []
+    for pos, line in enumerate(_read_lines(text)):
+        tab = line.find("\t")
+        if tab < 0:
+            raise IndexError("String index out of range: -1")      # substring(0, -1) in the reference
+        if int(line[:tab]) != pos:
+            raise ValueError("Your index must be dense and in order (see line %d)" % pos)
+        out.append(line[tab + 1:])
+    return out
+
+
+def java_format_f(v, precision: int = 6) -> str:
+    """String.format("%f") of a float: the decimal digits of (double)v rounded HALF_UP
+    (java.util.Formatter; differs from C's round-half-even on exact ties such as 5.0078125f)."""
+    v = float(np.float32(v))
+    if v != v:
+        return "NaN"
+    if v in (float("inf"), float("-inf")):
+        return "Infinity" if v > 0 else "-Infinity"
+    d = Decimal(v).quantize(Decimal(1).scaleb(-precision), rounding=ROUND_HALF_UP)
+    s = format(d, "f")
+    if d == 0 and np.signbit(v) and not s.startswith("-"):
+        s = "-" + s
+    return s
+
+
+def _read_text(path: str) -> str:
+    if path.endswith(".gz"):
+        with gzip.open(path, "rb") as f:
+            return f.read().decode("latin-1")
+    with open(path, "rb") as f:
+        return f.read().decode("latin-1")
+
+
+_TABLES: Dict[Tuple[str, float, int, int], SignatureTable] = {}     # tables stay resident in HBM across run() calls
+
+
+def _resident_table(path: str, device: int) -> SignatureTable:
+    st = os.stat(path)
+    key = (os.path.realpath(path), st.st_mtime, st.st_size, device)
+    tab = _TABLES.get(key)
+    if tab is None:
+        if path.endswith(".gz"):
+            with gzip.open(path, "rb") as f:
+                tab = SignatureTable.from_bytes(f.read(), device)
+        else:
+            tab = SignatureTable.open(path, device)
+        _TABLES[key] = tab
+    return tab
+
+
+class KmerGutsJava:
+    # KGJ:85-99
+    K = 8
+    CORE = 20 ** 7
+    MAX_ENCODED = 20 ** 8
+    GENETIC_CODE = tuple("KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF")
+    PROT_ALPHA = tuple("ACDEFGHIKLMNPQRSTVWY")
+    VERSION = 1
+    MAX_HITS_PER_SEQ = 40000
+    OI_BUFSZ = 5
+
+    # one batch handed to the GPU: below the C ABI's 2^32-256 windows per call
+    MAX_BATCH_CHARS = 1_500_000_000
+
+    def __init__(self, device: int = 0):
+        # KGJ:102-109
+        self.aa = False
+        self.orderConstraint = False
+        self.minHits = 5
+        self.minWeightedHits = 0
+        self.maxGap = 200
+        self.debug = False
+        self.device = device
+        self.last_stats: List[dict] = []
+
+    # ---- the static helpers a caller of the reference class could use (KGJ:111-318) ----
+    @staticmethod
+    def toAminoAcidOff(c: str) -> int:
+        i = "ACDEFGHIKLMNPQRSTVWY".find(c) if len(c) == 1 else -1
+        return i if i >= 0 else 20
+
+    _COMPL = {"a": "t", "A": "T", "c": "g", "C": "G", "g": "c", "G": "C", "t": "a", "u": "a", "T": "A", "U": "A",
+              "m": "k", "M": "K", "r": "y", "R": "Y", "w": "w", "W": "W", "s": "S", "S": "S", "y": "r", "Y": "R",
+              "k": "m", "K": "M", "b": "v", "B": "V", "d": "h", "D": "H", "h": "d", "H": "D", "v": "b", "V": "B",
+              "n": "n", "N": "N"}
+
+    @staticmethod
+    def compl(c: str) -> str:
+        return KmerGutsJava._COMPL.get(c, c)
+
+    @staticmethod
+    def revComp(data) -> str:
+        return "".join(KmerGutsJava._COMPL.get(c, c) for c in reversed("".join(data)))
+
+    @staticmethod
+    def encodedKmer(data, pos: int) -> int:
+        enc = 0
+        for i in range(8):
+            add = data[pos + i]
+            if add >= 20:
+                return -1
+            enc = enc * 20 + add
+        return enc
+
+    @staticmethod
+    def dnaChar(c: str) -> int:
+        return {"a": 0, "A": 0, "c": 1, "C": 1, "g": 2, "G": 2, "t": 3, "u": 3, "T": 3, "U": 3}.get(c, 4)
+
+    # ---- KmerGutsJavaServer.status (KmerGutsJavaServer.java:33-45) ----
+    def status(self) -> dict:
+        return {"state": "OK", "message": "", "version": "0.0.1", "git_url": "", "git_commit_hash": ""}
+
+    # ---- printInfoLine (KGJ:891-898) ----
+    def _info(self, message: str, pw, stdout: bool) -> None:
+        if self.debug:
+            pw.write(message + "\n")
+        if not stdout:
+            print(message)
+
+    # ---- run (KGJ:742-820) ----
+    def run(self, kmerTableDir: str, queryFastaFile: Optional[str], pw, stdout: bool) -> None:
+        self._info("Temp. directory: " + os.path.realpath(os.environ.get("TMPDIR", "/tmp")), pw, stdout)
+        table_path = os.path.join(kmerTableDir, "kmer.table.mem_map")
+        if os.path.exists(table_path + ".gz"):
+            table_path += ".gz"                                   # KGJ:750-753: the .gz wins
+        fn_path = os.path.join(kmerTableDir, "function.index")
+        if os.path.exists(fn_path + ".gz"):
+            fn_path += ".gz"
+        function_array = load_indexed_array(_read_text(fn_path))
+        text = sys.stdin.read() if queryFastaFile is None else _read_text(queryFastaFile)
+        tab = _resident_table(table_path, self.device)
+
+        t1 = time.time()
+        ids: List[str] = []
+        seqs: List[bytes] = []
+        read_fasta(text, lambda name, seq, descr: (ids.append(name), seqs.append(seq.encode("latin-1"))))
+        self._info("Preparation time: %d ms." % int((time.time() - t1) * 1000), pw, stdout)
+
+        # queryIdToLen / hitCnts are maps (KGJ:772, 805-809): a repeated id is reported once, at the place
+        # of its first record, with the length and the hits of its last record
+        last_of: Dict[str, int] = {}
+        for k, name in enumerate(ids):
+            last_of[name] = k
+        order = [last_of[name] for name in last_of]
+
+        t2 = time.time()
+        params = Params(aa=self.aa, order_constraint=self.orderConstraint, min_hits=self.minHits,
+                        min_weighted_hits=self.minWeightedHits, max_gap=self.maxGap)
+        per = 1 if self.aa else 6
+        results = {}                    # record index -> (calls of its containers, otu record)
+        self.last_stats = []
+        batch: List[int] = []
+        size = 0
+
+        def flush():
+            nonlocal batch, size
+            if not batch:
+                return
+            off = np.zeros(len(batch) + 1, dtype=np.int64)
+            np.cumsum([len(seqs[k]) for k in batch], out=off[1:])
+            buf = np.frombuffer(b"".join(seqs[k] for k in batch), dtype=np.uint8)
+            with tab.scan(buf, off, params) as r:
+                calls, ccs, otu = r.calls(), r.container_call_start(), r.otu()
+                self.last_stats.append(r.stats)
+            for j, k in enumerate(batch):
+                results[k] = ([calls[ccs[j * per + f]:ccs[j * per + f + 1]] for f in range(per)], otu[j])
+            batch, size = [], 0
+
+        for k in order:
+            if batch and size + len(seqs[k]) > self.MAX_BATCH_CHARS:
+                flush()
+            batch.append(k)
+            size += len(seqs[k])
+        flush()
+        self._info("Lookup time: %d ms." % int((time.time() - t2) * 1000), pw, stdout)
+
+        t3 = time.time()
+        for k in order:
+            calls, otu = results[k]
+            self.write_record(pw, ids[k], len(seqs[k]), calls, otu, function_array)
+        pw.flush()
+        self._info("Grouping time: %d ms." % int((time.time() - t3) * 1000), pw, stdout)
+
+    def write_record(self, pw, name: str, ln: int, calls_per_container, otu, function_array) -> None:
+        """The report of one sequence: processSeq / processAASeq + tabulateOtuDataForContig
+        (KGJ:526-558, 516-524).  calls_per_container: 1 (protein) or 6 (+0 +1 +2 -0 -1 -2) CALL record arrays."""
+        w = pw.write
+        if self.aa:
+            w("PROTEIN-ID\t%s\t%d\n" % (name, ln))                              # KGJ:529
+            self._print_calls(calls_per_container[0], function_array, w)
+        else:
+            w("processing %s[%d]\n" % (name, ln))                               # KGJ:541
+            for f in range(6):
+                w("TRANSLATION\t%s\t%d\t%s\t%d\n" % (name, ln, "+-"[f // 3], f % 3))   # KGJ:545
+                self._print_calls(calls_per_container[f], function_array, w)
+        w("OTU-COUNTS\t%s[%d]" % (name, ln))                                    # KGJ:518-522
+        for j in range(int(otu["n"])):
+            w("\t%d-%d" % (int(otu["count"][j]), int(otu["oI"][j])))
+        w("\n")
+
+    @staticmethod
+    def _print_calls(calls, function_array, w) -> None:
+        for c in calls:                                                             # KGJ:398-404
+            fi = int(c["fI"])
+            if fi < 0 or fi >= len(function_array):
+                raise IndexError("Index: %d, Size: %d" % (fi, len(function_array)))  # functionArray.get() throws
+            w("CALL\t%d\t%d\t%d\t%d\t%s\t%s\n" % (int(c["start"]), int(c["end"]), int(c["count"]), fi,
+                                                 function_array[fi], java_format_f(c["weightedHits"])))
+
+    # ---- main (KGJ:560-654) ----
+    USAGE = (
+        "Usage: kmer_guts [options] -D DataDir",
+        "Arguments:",
+        " -a - (optional) amino acids in input FASTA (default is DNA)",
+        " -d - (optional) print debug messages",
+        " -m - (optional) min. number of hits in result (integer, default = 5)",
+        " -M - (optional) min. sum of hit weights (integer, default = 0)",
+        " -O - (optional) order constraint (don't use order by default)",
+        " -g - (optional) max. gap between hits to be joined (integer, default = 200)",
+        " -D - (required) data directory with kmer-table and function-index files",
+        " -q - (optional) query fasta file (STDIN if not defined)",
+        " -o - (optional) output file (STDOUT if not defined)",
+        " -t - (optional) temporary directory (system one is used by default)",
+        " -l - (optional) limit for input Kmer array (long, default = 20,000,000)",
+    )
+
+    @classmethod
+    def main(cls, args: List[str], device: int = 0) -> None:
+        kmer_table_dir = query = output = None
+        inst = cls(device)
+        try:
+            params = list(args)
+            while params:
+                param = params.pop(0)
+                if not param.startswith("-"):
+                    raise ValueError("Parameter name should start from '-': " + param)
+                param = param[1:]
+                if len(param) != 1:
+                    raise ValueError("Unknown parameter: -" + param)
+                ch = param
+                if ch == "a":
+                    inst.aa = True
+                elif ch == "d":
+                    inst.debug = True
+                elif ch == "m":
+                    inst.minHits = _parse_int(params.pop(0) if params else None)
+                elif ch == "M":
+                    inst.minWeightedHits = _parse_int(params.pop(0) if params else None)
+                elif ch == "O":
+                    inst.orderConstraint = True
+                elif ch == "g":
+                    inst.maxGap = _parse_int(params.pop(0) if params else None)
+                elif ch == "D":
+                    kmer_table_dir = params.pop(0) if params else None
+                elif ch == "q":
+                    query = params.pop(0) if params else None
+                elif ch == "o":
+                    output = params.pop(0) if params else None
+                elif ch in "tl":
+                    # KGJ:605-611: both cases consume their value(s) and fall through to the default branch
+                    if ch == "t" and params:
+                        params.pop(0)
+                    _parse_int(params.pop(0) if params else None)          # Long.parseLong(params.poll())
+                    raise ValueError("Unknown parameter: -" + param)
+                else:
+                    raise ValueError("Unknown parameter: -" + param)
+            if kmer_table_dir is None:
+                raise ValueError("-D parameter is required")
+        except Exception as ex:                                   # KGJ:616-636: print usage, then carry on
+            print("Error: " + str(ex))
+            for line in cls.USAGE:
+                print(line)
+        if kmer_table_dir is None:
+            raise TypeError("kmerTableDir is null")               # new File((String) null) throws in the reference
+        if query is None:
+            raise TypeError("queryFastaFile is null")             # KGJ:647: new File(null) -> NullPointerException
+        if output is not None:
+            with open(output, "w", newline="") as pw:
+                inst.run(kmer_table_dir, query, pw, False)
+        else:
+            inst.run(kmer_table_dir, query, sys.stdout, True)
+            sys.stdout.flush()
+
+
+def main(argv: Optional[List[str]] = None) -> None:
+    KmerGutsJava.main(sys.argv[1:] if argv is None else argv)
+
+
+if __name__ == "__main__":
+    main()

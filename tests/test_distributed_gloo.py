@@ -1,0 +1,70 @@
+"""World-size-2 rehearsal of the multi-GPU layer on CPU (gloo): shard whole sequences over ranks,
+scan each shard independently (the oracle stands in for the GPU here -- this test is about the
+sharding and the gather, not the kernels), gather CALL / OTU / hit records to rank 0, restore the
+original order, compare with the unsharded result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dna, tmp):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from kmergutsjava_amd import distributed as kd, synth
+    from oracle import kgo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seq, off, rec, keys = synth.high_density_config(11, 45, 8009, 2500, seed=777, dna=dna)
+        img = synth.table_image(rec)
+        sb = seq.numpy()
+        per = 6 if dna else 1
+        lens = np.diff(off)
+        shards = kd.shard_sequences(lens, world)
+        assert sorted(np.concatenate(shards).tolist()) == list(range(len(lens)))
+        mine = shards[rank]
+        s_seq, s_off = kd.take_shard(sb, off, mine)
+        loc = kgo.run(img, s_seq, s_off, aa=not dna, lookup_mode=1)
+        local = {k: loc[k] for k in ("calls", "container_call_start", "otu", "hits", "container_hit_start")}
+        got = kd.gather_records(local, mine, len(lens), per, device="cpu")
+        if rank == 0:
+            whole = kgo.run(img, sb, off, aa=not dna, lookup_mode=1)
+            for k in ("calls", "container_call_start", "otu", "hits", "container_hit_start"):
+                assert got[k].tobytes() == whole[k].tobytes(), k
+            assert len(whole["calls"]) > 5
+            open(os.path.join(tmp, "ok"), "w").write("ok")
+        else:
+            assert got is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dna", [True, False])
+def test_shard_and_gather_world2(tmp_path, dna, oracle):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, dna, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_shard_balance():
+    from kmergutsjava_amd import distributed as kd, synth
+    lens = synth.contig_mix_lengths(50_000_000, 301)
+    for w in (2, 4, 8):
+        sh = kd.shard_sequences(lens, w)
+        loads = np.array([lens[i].sum() for i in sh])
+        assert loads.max() / loads.mean() < 1.05, (w, loads)
+        assert sum(len(i) for i in sh) == len(lens)

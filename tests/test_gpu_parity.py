@@ -246,3 +246,67 @@ def test_midsize_persistent_waves(hp, oracle):
             finally:
                 for k in ("KG_SCAN_GRID", "KG_SCAN_RPG", "KG_STAGE_CHUNK"):
                     os.environ.pop(k, None)
+
+
+def _ecoli(name):
+    import gzip, os
+    from kmergutsjava_amd.kmer_guts_java import read_fasta
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+    ids, seqs = [], []
+    read_fasta(gzip.open(path, "rb").read().decode("latin-1"), lambda n, s, d: (ids.append(n), seqs.append(s.encode())))
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    np.cumsum([len(s) for s in seqs], out=off[1:])
+    return ids, b"".join(seqs), off
+
+
+def test_ecoli_reference_fixtures(hp, oracle):
+    """The reference's own test inputs (test/data/Ecoli_K12_W3110.{faa,fna}.gz; no expected output exists)
+    against a synthetic table whose signatures are partly the proteome's own 8-mers, so that the genome's
+    genes produce real CALLs in DNA mode.  HIP == oracle (literal merge-join), record for record."""
+    from kmergutsjava_amd import synth
+    ids_p, prot, off_p = _ecoli("Ecoli_K12_W3110.faa.gz")
+    assert len(ids_p) == 13645 and int(off_p[-1]) == 4147102
+    ids_g, dna, off_g = _ecoli("Ecoli_K12_W3110.fna.gz")
+    assert len(ids_g) == 1 and int(off_g[-1]) == 4646332
+    codes = synth.aa_codes(torch.frombuffer(bytearray(prot), dtype=torch.uint8))
+    vals = synth.encode_windows_aa(codes)
+    vals = vals[vals >= 0]
+    own = vals[synth._uniform(71, 0, 400000, int(vals.numel()), "cpu")]
+    keys = torch.unique(torch.cat([own, synth.random_keys(400000, 72)]))
+    fn = (synth._lsr(synth.splitmix64(73, keys // 20 ** 5), 3) % 500).to(torch.int32)    # neighbours share a function
+    otu, avg, _, wt = synth.payload_of(keys, 74, n_otu=12)
+    rec, placed = synth.build_table(keys, (otu, avg, fn, wt), 2_000_003)
+    img = _img(rec)
+    with hp.SignatureTable.from_bytes(img) as tab:
+        ora = oracle.run(img, prot, off_p, aa=True, lookup_mode=0)
+        with tab.scan(prot, off_p, hp.Params(aa=True, counters=True)) as r:
+            assert_same_records(r, ora, "E. coli proteome")
+            assert r.stats["windows_valid"] == ora["windows_valid"]
+        assert len(ora["hits"]) > 300000
+        ora = oracle.run(img, dna, off_g, lookup_mode=0, min_hits=3)
+        with tab.scan(dna, off_g, hp.Params(min_hits=3, counters=True)) as r:
+            assert_same_records(r, ora, "E. coli genome")
+            assert r.stats["windows_valid"] == ora["windows_valid"]
+        assert len(ora["calls"]) > 100
+
+
+def test_cli_gz_data_dir_and_duplicate_ids(tmp_path):
+    """KmerGutsJava.main on a gzipped data directory (KGJ:750-758) and a gzipped FASTA (KGJ:764-766);
+    a repeated id is reported once, at its first place, with its last record's data (KGJ:772, 805-809)."""
+    import gzip
+    from oracle import kgj_model as M
+    from kmergutsjava_amd import synth, KmerGutsJava
+    seq, off, rec, keys = synth.high_density_config(5, 40, 1009, 400, seed=31, dna=True)
+    img = synth.table_image(rec)
+    sb = seq.numpy().tobytes()
+    names = ["a", "b", "a", "c", "b"]
+    fa = "".join(">%s x\n%s\n" % (names[k], sb[off[k]:off[k + 1]].decode()) for k in range(5))
+    synth.write_data_dir(str(tmp_path / "d"), img, 64, gz=True)
+    with gzip.open(tmp_path / "q.fa.gz", "wt") as f:
+        f.write(fa)
+    KmerGutsJava.main(["-D", str(tmp_path / "d"), "-q", str(tmp_path / "q.fa.gz"), "-o", str(tmp_path / "o.txt"), "-m", "3"])
+    fn = ["synthetic function %d" % i for i in range(64)]
+    want = M.Model(min_hits=3).run(img, fn, fa)
+    got = (tmp_path / "o.txt").read_text()
+    assert got == want
+    assert got.count("processing ") == 3 and "CALL\t" in got
