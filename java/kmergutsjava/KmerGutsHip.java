@@ -1,0 +1,73 @@
+package kmergutsjava;
+
+import com.sun.jna.Library;
+import com.sun.jna.Native;
+import com.sun.jna.Pointer;
+import com.sun.jna.Structure;
+import com.sun.jna.ptr.PointerByReference;
+
+import java.util.Arrays;
+import java.util.List;
+
+/**
+ * JNA binding of libkmerguts_hip.so (C ABI: include/kmerguts_hip.h), the MI355X implementation of the
+ * kmer_guts hot path.  jna-3.4.0.jar is already on the reference's classpath (build.xml:27), so a
+ * maintainer adds this one file and the call site shown in INTEGRATION.md.
+ *
+ * NOT COMPILED IN THIS REPOSITORY'S BUILD IMAGE (no JDK there); it is kept mechanical on purpose:
+ * one Java method per exported C function, structures field for field.
+ */
+public interface KmerGutsHip extends Library {
+    KmerGutsHip LIB = (KmerGutsHip) Native.loadLibrary("kmerguts_hip", KmerGutsHip.class);
+
+    int KG_OK = 0;
+    int KG_F_COUNTERS = 1;
+    int KG_F_SKIP_AGGREGATE = 2;
+
+    /** struct kg_params: the instance fields the hot path reads (KmerGutsJava.java:102-106). */
+    class KgParams extends Structure {
+        public int aa, order_constraint, min_hits, min_weighted_hits, max_gap, flags;
+        @Override protected List<String> getFieldOrder() {
+            return Arrays.asList("aa", "order_constraint", "min_hits", "min_weighted_hits", "max_gap", "flags");
+        }
+    }
+
+    /** struct kg_stats */
+    class KgStats extends Structure {
+        public long n_seqs, n_containers, n_blocks, n_hits, n_calls, residues, windows, windows_valid,
+                slots_inspected, table_bytes;
+        public float ms_scan, ms_order, ms_aggregate, ms_total;
+        public int scan_launches, reserved;
+        @Override protected List<String> getFieldOrder() {
+            return Arrays.asList("n_seqs", "n_containers", "n_blocks", "n_hits", "n_calls", "residues", "windows",
+                    "windows_valid", "slots_inspected", "table_bytes", "ms_scan", "ms_order", "ms_aggregate",
+                    "ms_total", "scan_launches", "reserved");
+        }
+    }
+
+    // replaces readKmerTableHeader + the table stream of lookup (KmerGutsJava.java:924-942, 944-1034)
+    int kg_table_open(String path, int device, PointerByReference out);
+    int kg_table_from_memory(Pointer image, long nbytes, int device, PointerByReference out);
+    int kg_table_from_device(Pointer dEntries, long numSigs, int device, PointerByReference out);
+    int kg_table_info(Pointer table, long[] numSigs, long[] entrySize, long[] version, long[] occupied);
+    void kg_table_close(Pointer table);
+
+    // replaces prepareQuery/addKmers, the query sort, lookup and gatherHits/processSetOfHits
+    // (KmerGutsJava.java:1051-1074, 900-922, 1076-1095, 944-1034, 385-514) for a batch of sequences
+    int kg_scan(Pointer table, KgParams params, byte[] seq, long[] offsets, long nSeqs, PointerByReference out);
+    int kg_scan_device(Pointer table, KgParams params, Pointer dSeq, long[] offsets, long nSeqs, PointerByReference out);
+
+    int kg_result_stats(Pointer result, KgStats out);
+    Pointer kg_result_hits(Pointer result);                  // kg_hit[n_hits]   24 B each
+    Pointer kg_result_container_hit_start(Pointer result);   // int64[n_containers + 1]
+    Pointer kg_result_calls(Pointer result);                 // kg_call[n_calls] 24 B each
+    Pointer kg_result_container_call_start(Pointer result);  // int64[n_containers + 1]
+    Pointer kg_result_otu(Pointer result);                   // kg_otu[n_seqs]   44 B each
+    Pointer kg_result_device_hits(Pointer result);
+    Pointer kg_result_device_calls(Pointer result);
+    Pointer kg_result_device_otu(Pointer result);
+    void kg_result_free(Pointer result);
+
+    String kg_last_error();
+    String kg_version();
+}

@@ -102,14 +102,22 @@ __device__ __forceinline__ Tags16 load_tags(const uint8_t *p)
     return r;
 }
 
-// First slot i in 0..15 whose tag is EMPTY or == fp.  Returns 16 if none.  *is_empty tells which.
-__device__ __forceinline__ int first_stop(const Tags16 &x, uint32_t fp, bool *is_empty)
+// First slot i in skip..15 whose tag is EMPTY or == fp (bytes below `skip` are ignored).  Returns 16 if
+// none.  *is_empty tells which.
+__device__ __forceinline__ int first_stop(const Tags16 &x, uint32_t fp, bool *is_empty, uint32_t skip = 0)
 {
     const uint32_t fpw = fp * 0x01010101u;
     uint32_t e0 = zero_bytes(~x.w[0]), e1 = zero_bytes(~x.w[1]), e2 = zero_bytes(~x.w[2]), e3 = zero_bytes(~x.w[3]);
     uint32_t f0 = zero_bytes(x.w[0] ^ fpw), f1 = zero_bytes(x.w[1] ^ fpw), f2 = zero_bytes(x.w[2] ^ fpw), f3 = zero_bytes(x.w[3] ^ fpw);
     uint64_t elo = ((uint64_t)e1 << 32) | e0, ehi = ((uint64_t)e3 << 32) | e2;
     uint64_t slo = elo | (((uint64_t)f1 << 32) | f0), shi = ehi | (((uint64_t)f3 << 32) | f2);
+    if (skip) {
+        // keep only the stop bits of bytes >= skip
+        const uint64_t keep_lo = skip >= 8 ? 0ull : ~0ull << (8 * skip);
+        const uint64_t keep_hi = skip <= 8 ? ~0ull : ~0ull << (8 * (skip - 8));
+        slo &= keep_lo;
+        shi &= keep_hi;
+    }
     if (slo) {
         int b = __builtin_ctzll(slo);
         *is_empty = (elo >> b) & 1;
@@ -122,6 +130,16 @@ __device__ __forceinline__ int first_stop(const Tags16 &x, uint32_t fp, bool *is
     }
     *is_empty = false;
     return 16;
+}
+
+// A 16-byte window starting at `slot` straddles a 128-byte line (= one more L2-miss request, the unit the
+// memory side fetches) when slot % 128 > 112.  Then read the aligned 16-byte chunk that holds `slot` instead
+// and ignore its first slot % 16 bytes: fewer slots of look-ahead in 12 % of the probes, 10 % fewer requests.
+__device__ __forceinline__ uint64_t probe_window(uint64_t slot, uint32_t *skip)
+{
+    const bool straddles = ((uint32_t)slot & 127u) > 112u;
+    *skip = straddles ? ((uint32_t)slot & 15u) : 0u;
+    return straddles ? (slot & ~15ull) : slot;
 }
 
 struct Entry { int64_t key; int32_t oI, avg, fI; float wt; };
@@ -302,7 +320,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
 
             // ---- probe: home slot, 16 tags per load, records touched only on a fingerprint match
             uint64_t cand[RPG];     // slot under examination
-            uint32_t fp[RPG];
+            uint32_t fp[RPG], skip[RPG];
             Tags16 tg[RPG];
             uint64_t home[COUNTERS ? RPG : 1];
 #pragma unroll
@@ -311,6 +329,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
                 fp[q] = tag_of(val[q]);
                 if (COUNTERS) { home[q] = cand[q]; if (valid[q]) ctr_valid++; }   // query k-mers (KGJ:913-920)
                 valid[q] = valid[q] && cand[q] < tab.limit;     // beyond the stream: EOF, not found, nothing inspected
+                cand[q] = probe_window(cand[q], &skip[q]);
                 if (valid[q]) tg[q] = load_tags(tab.tags + cand[q]);
             }
             // state per row: resolved, candidate at cand[q] (bit in st1), or keep walking from cand[q] (bit in pend)
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
                 if (COUNTERS) stop[q] = cand[q];
                 if (valid[q]) {
                     bool emp;
-                    int i = first_stop(tg[q], fp[q], &emp);
+                    int i = first_stop(tg[q], fp[q], &emp, skip[q]);
                     if (i == 16) { pend |= 1u << q; cand[q] += 16; }
                     else {
                         cand[q] += (uint64_t)i;
