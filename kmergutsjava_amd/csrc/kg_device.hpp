@@ -197,8 +197,252 @@ struct __attribute__((aligned(16))) WaveLdsAa {
     uint8_t lut[256];
 };
 
+template <bool AA> struct WaveLds;
+template <> struct WaveLds<false> { typedef WaveLdsDna type; };
+template <> struct WaveLds<true> { typedef WaveLdsAa type; };
+
+// once per wave: the lookup tables that live in the wave's LDS region
+template <bool AA>
+__device__ __forceinline__ void encode_init(typename WaveLds<AA>::type &l, int lane)
+{
+    if constexpr (AA) {
+        // toAminoAcidOff (KGJ:111-175) as a 256-entry table: uppercase letters only
+        for (int b = lane; b < 256; b += 64) l.lut[b] = (uint8_t)aa_code_of((char)b);
+    } else {
+        if (lane < 16) l.t16[lane] = kCodon16[lane];
+    }
+    wave_sync();
+}
+
+// Stage one block's characters and leave the 4-residue half codes in LDS (all lanes of the wave).
+template <bool AA>
+__device__ __forceinline__ void encode_block(typename WaveLds<AA>::type &l, const uint8_t *__restrict__ seq,
+                                             const BlockDesc &bd, int lane)
+{
+    const uint64_t soff = bd.soff;
+    const uint32_t L = bd.len, j = bd.j;
+    if constexpr (AA) {
+        // ---- protein: windows i = 64j + lane
+        const uint32_t w0 = j * kAaWinPerBlock;
+        const uint32_t nload = min(71u, L - w0);
+        for (uint32_t q = lane; q < 72; q += 64) {
+            uint32_t c = q < nload ? seq[soff + w0 + q] : 0u;
+            l.code[q] = l.lut[c];
+        }
+        wave_sync();
+        for (uint32_t q = lane; q < 68; q += 64) {
+            uint32_t c0 = l.code[q], c1 = l.code[q + 1], c2 = l.code[q + 2], c3 = l.code[q + 3];
+            bool ok = (c0 < 20) & (c1 < 20) & (c2 < 20) & (c3 < 20);
+            l.H4[q] = ok ? c0 * 8000u + c1 * 400u + c2 * 20u + c3 : kInvalid;
+        }
+        wave_sync();
+    } else {
+        // ---- DNA: stage 215 bases, derive codon codes for both strands, then 4-codon half codes
+        const uint32_t ts = j * kDnaPosPerBlock;
+        const uint32_t nload = min(215u, L - ts);
+        for (uint32_t q = lane; q < 232; q += 64) {
+            uint32_t c = q < nload ? seq[soff + ts + q] : (uint32_t)'N';
+            l.bc[q] = (uint8_t)dna_code(c);
+        }
+        wave_sync();
+        for (uint32_t q = lane; q < 213; q += 64) {
+            uint32_t b0 = l.bc[q], b1 = l.bc[q + 1], b2 = l.bc[q + 2];
+            bool ok = (b0 < 4) & (b1 < 4) & (b2 < 4);
+            // translate (KGJ:320-343): codon index c1*16+c2*4+c3; non-ACGTU -> 'x' -> code 20
+            uint32_t f = (l.t16[(b0 * 4 + b1) & 15] >> ((b2 & 3) * 5)) & 31u;
+            // reverse strand (KGJ:263-272 + 320-343): codon = compl(b2) compl(b1) compl(b0); compl code = 3 - code
+            uint32_t r = (l.t16[((3 - b2) * 4 + (3 - b1)) & 15] >> (((3 - b0) & 3) * 5)) & 31u;
+            l.F[q] = (uint8_t)(ok ? f : 20u);
+            l.R[q] = (uint8_t)(ok ? r : 20u);
+        }
+        wave_sync();
+        for (uint32_t q = lane; q < 204; q += 64) {
+            uint32_t f0 = l.F[q], f1 = l.F[q + 3], f2 = l.F[q + 6], f3 = l.F[q + 9];
+            uint32_t r0 = l.R[q], r1 = l.R[q + 3], r2 = l.R[q + 6], r3 = l.R[q + 9];
+            bool okf = (f0 < 20) & (f1 < 20) & (f2 < 20) & (f3 < 20);
+            bool okr = (r0 < 20) & (r1 < 20) & (r2 < 20) & (r3 < 20);
+            l.H[q] = okf ? f0 * 8000u + f1 * 400u + f2 * 20u + f3 : kInvalid;
+            // on the '-' strand the codon over the highest bases comes first
+            l.G[q] = okr ? r3 * 8000u + r2 * 400u + r1 * 20u + r0 : kInvalid;
+        }
+        wave_sync();
+    }
+}
+
+// encodedKmer (KGJ:274-292) of the lane's window in row r (wave-uniform; DNA: strand r/3, phase r%3).
+template <bool AA>
+__device__ __forceinline__ bool row_value(const typename WaveLds<AA>::type &l, int r, int lane, const BlockDesc &bd,
+                                          uint64_t *val)
+{
+    if constexpr (AA) {
+        uint32_t hi = l.H4[lane], lo = l.H4[lane + 4];
+        uint32_t i = bd.j * kAaWinPerBlock + lane;
+        *val = (uint64_t)hi * 160000ull + lo;
+        // queried iff i < len - 8 (KGJ:912: i < pIseq.length - K -- the last window is never queried)
+        return (hi != kInvalid) & (lo != kInvalid) & ((uint64_t)i + 8 < (uint64_t)bd.len);
+    } else {
+        const bool minus = r >= 3;
+        const uint32_t pl = 3u * lane + (uint32_t)(minus ? r - 3 : r);
+        const uint32_t *hc = minus ? l.G : l.H;
+        uint32_t a = hc[pl], b = hc[pl + 12];
+        // '+': first four codons are the high half; '-': the codons over the higher bases are
+        *val = minus ? (uint64_t)b * 160000ull + a : (uint64_t)a * 160000ull + b;
+        return (a != kInvalid) & (b != kInvalid);
+    }
+}
+
+// Index of row r of block bd in the container-major row order (rows of one container are contiguous), the
+// container it belongs to and the residue index of lane 0's window / its direction.
+template <bool AA>
+__device__ __forceinline__ uint32_t row_index(const BlockDesc &bd, uint32_t it, int r)
+{
+    if (AA) return it;
+    const uint32_t vbase = 6u * bd.ibase;
+    if (r < 3) return vbase + (uint32_t)r * bd.nk + bd.j;
+    return vbase + (3u + (bd.len - (uint32_t)(r - 3)) % 3u) * bd.nk + (bd.nk - 1u - bd.j);
+}
+
+template <bool AA>
+__device__ __forceinline__ void row_record_key(const BlockDesc &bd, int r, int lane, uint32_t *container, int32_t *pos)
+{
+    if (AA) {
+        *container = bd.seq;
+        *pos = (int32_t)(bd.j * kAaWinPerBlock + lane);
+    } else if (r < 3) {
+        // '+' strand: frame r (block start is a multiple of 3), residue index 64j + lane
+        *container = bd.seq * 6u + (uint32_t)r;
+        *pos = (int32_t)(bd.j * 64u + lane);
+    } else {
+        // '-' strand: the window over forward bases p..p+23 starts at reverse-complement base b' = L-24-p,
+        // i.e. frame b'%3, residue b'/3 (KGJ:1068-1072).  24 % 3 == 0 and the block start is a multiple of 3,
+        // so the frame depends on the row only.
+        const uint32_t f = (uint32_t)(r - 3);
+        *container = bd.seq * 6u + 3u + (bd.len - f) % 3u;
+        *pos = (int32_t)((bd.len - 24u - f - bd.j * kDnaPosPerBlock) / 3u) - (int32_t)lane;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
-// The scan kernel.  ROWS = 6 (DNA) or 1 (AA).  Waves are persistent and stride over the blocks.
+// Probe N independent query k-mers per lane (KGJ:944-1034 semantics: from the home slot forward until the
+// k-mer, an empty slot or the end of the stream; never wrap).  16 tags per load, records touched only on a
+// fingerprint match; the rare longer walks share one copy of the generic walk, rows picked by register muxes.
+// On return bit q of the result is set iff query q was found, with ent[q] = the record's payload.
+template <int N, bool COUNTERS>
+__device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t (&val)[N], bool (&valid)[N],
+                                            Payload (&ent)[N], unsigned long long &ctr_valid,
+                                            unsigned long long &ctr_slots)
+{
+    uint64_t cand[N];     // slot under examination
+    uint32_t fp[N], skip[N];
+    Tags16 tg[N];
+    uint64_t home[COUNTERS ? N : 1];
+#pragma unroll
+    for (int q = 0; q < N; q++) {
+        cand[q] = home_slot(val[q], tab);
+        fp[q] = tag_of(val[q]);
+        if (COUNTERS) { home[q] = cand[q]; if (valid[q]) ctr_valid++; }   // query k-mers (KGJ:913-920)
+        valid[q] = valid[q] && cand[q] < tab.limit;     // beyond the stream: EOF, not found, nothing inspected
+        cand[q] = probe_window(cand[q], &skip[q]);
+        if (valid[q]) tg[q] = load_tags(tab.tags + cand[q]);
+    }
+    // state per row: resolved, candidate at cand[q] (bit in st1), or keep walking from cand[q] (bit in pend)
+    uint32_t st1 = 0, pend = 0;
+    uint64_t stop[COUNTERS ? N : 1];
+#pragma unroll
+    for (int q = 0; q < N; q++) {
+        if (COUNTERS) stop[q] = cand[q];
+        if (valid[q]) {
+            bool emp;
+            int i = first_stop(tg[q], fp[q], &emp, skip[q]);
+            if (i == 16) { pend |= 1u << q; cand[q] += 16; }
+            else {
+                cand[q] += (uint64_t)i;
+                if (COUNTERS) stop[q] = cand[q];
+                if (!emp) st1 |= 1u << q;
+            }
+        }
+    }
+    uint32_t foundm = 0;
+    {
+        Entry full[N];
+#pragma unroll
+        for (int q = 0; q < N; q++)
+            if (st1 & (1u << q)) full[q] = load_entry(tab, cand[q]);
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+            if (st1 & (1u << q)) {
+                if (full[q].key == (int64_t)val[q]) foundm |= 1u << q;
+                else { pend |= 1u << q; cand[q] += 1; }       // fingerprint collision: keep walking
+            }
+            ent[q].oI = full[q].oI; ent[q].avg = full[q].avg; ent[q].fI = full[q].fI; ent[q].wt = full[q].wt;
+        }
+    }
+    while (__ballot(pend != 0)) {
+        if (pend) {
+            const int r = __builtin_ctz(pend);
+            uint64_t v = val[0], s = cand[0];
+            uint32_t f = fp[0];
+#pragma unroll
+            for (int q = 1; q < N; q++)
+                if (r == q) { v = val[q]; s = cand[q]; f = fp[q]; }
+            bool done = false, hit = false;
+            Entry e;
+            e.key = 0; e.oI = e.avg = e.fI = 0; e.wt = 0.f;
+            if (s >= tab.limit) { done = true; s = tab.limit; }
+            else {
+                Tags16 x = load_tags(tab.tags + s);
+                bool emp;
+                int i = first_stop(x, f, &emp);
+                if (i == 16) s += 16;
+                else if (emp) { done = true; s += (uint64_t)i; }
+                else {
+                    s += (uint64_t)i;
+                    e = load_entry(tab, s);
+                    if (e.key == (int64_t)v) done = hit = true;
+                    else s += 1;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < N; q++) {
+                if (r == q) {
+                    cand[q] = s;
+                    if (done) {
+                        if (COUNTERS) stop[q] = s;
+                        if (hit) { ent[q].oI = e.oI; ent[q].avg = e.avg; ent[q].fI = e.fI; ent[q].wt = e.wt; foundm |= 1u << q; }
+                    }
+                }
+            }
+            if (done) pend &= pend - 1;
+        }
+    }
+    if (COUNTERS) {
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+            if (valid[q]) {
+                uint64_t last = stop[q] < tab.limit ? stop[q] + 1 : tab.limit;
+                ctr_slots += last - home[q];
+            }
+        }
+    }
+    return foundm;
+}
+
+// wave reduction of the two counters, one atomic pair per wave
+__device__ __forceinline__ void flush_counters(unsigned long long ctr_valid, unsigned long long ctr_slots,
+                                               unsigned long long *ctr, int lane)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        ctr_valid += __shfl_down(ctr_valid, off);
+        ctr_slots += __shfl_down(ctr_slots, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&ctr[0], ctr_valid);
+        atomicAdd(&ctr[1], ctr_slots);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The direct scan kernel.  ROWS = 6 (DNA) or 1 (AA).  Waves are persistent and stride over the blocks.
 //
 // All pointers are direct kernel arguments (global address space: global_load, counted vmcnt);
 // pointers inside a by-value struct would be generic and compile to flat_load + vmcnt(0).
@@ -207,6 +451,7 @@ struct __attribute__((aligned(16))) WaveLdsAa {
 // and hands them out to its successive blocks (one returning atomic per ~chunk/hits-per-block
 // blocks instead of one per block; a single word sustains only ~90 returning atomics per us).
 // The unused tail of a chunk is a hole; block_stage_base[] says where each block's records are.
+//
 // RPG = rows probed together by one lane (memory-level parallelism per lane vs registers per wave);
 // a block's ROWS/RPG row groups are staged independently (block_stage_base has one entry per group).
 template <bool AA, bool COUNTERS, int RPG>
@@ -219,8 +464,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
     constexpr int ROWS = AA ? 1 : 6;
     constexpr int NG = ROWS / RPG;
     static_assert(ROWS % RPG == 0, "RPG must divide the row count");
-    __shared__ WaveLdsDna lds_dna[AA ? 1 : kWavesPerWG];
-    __shared__ WaveLdsAa lds_aa[AA ? kWavesPerWG : 1];
+    __shared__ typename WaveLds<AA>::type lds[kWavesPerWG];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerWG + wave);
@@ -228,15 +472,8 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
     TableView tab;
     tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic;
 
-    WaveLdsDna &ld = lds_dna[AA ? 0 : wave];
-    WaveLdsAa &la = lds_aa[AA ? wave : 0];
-    if (AA) {
-        // toAminoAcidOff (KGJ:111-175) as a 256-entry table: uppercase letters only
-        for (int b = lane; b < 256; b += 64) la.lut[b] = (uint8_t)aa_code_of((char)b);
-    } else {
-        if (lane < 16) ld.t16[lane] = kCodon16[lane];
-    }
-    wave_sync();
+    typename WaveLds<AA>::type &l = lds[wave];
+    encode_init<AA>(l, lane);
 
     unsigned long long ctr_valid = 0, ctr_slots = 0;
     unsigned long long res_at = 0, res_end = 0;          // this wave's staging reservation (uniform)
@@ -244,176 +481,16 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
     for (uint32_t it_v = wave_global; it_v < n_blocks; it_v += n_waves) {
         const uint32_t it = __builtin_amdgcn_readfirstlane(it_v);
         const BlockDesc bd = blocks[it];
-        const uint64_t soff = bd.soff;
-        const uint32_t L = bd.len, j = bd.j, nk = bd.nk;
+        encode_block<AA>(l, seq, bd, lane);
 
-        if (AA) {
-            // ---- protein: windows i = 64j + lane, queried iff i < len - 8 (KGJ:912: i < pIseq.length - K)
-            const uint32_t w0 = j * kAaWinPerBlock;
-            const uint32_t nload = min(71u, L - w0);
-            for (uint32_t q = lane; q < 72; q += 64) {
-                uint32_t c = q < nload ? seq[soff + w0 + q] : 0u;
-                la.code[q] = la.lut[c];
-            }
-            wave_sync();
-            for (uint32_t q = lane; q < 68; q += 64) {
-                uint32_t c0 = la.code[q], c1 = la.code[q + 1], c2 = la.code[q + 2], c3 = la.code[q + 3];
-                bool ok = (c0 < 20) & (c1 < 20) & (c2 < 20) & (c3 < 20);
-                la.H4[q] = ok ? c0 * 8000u + c1 * 400u + c2 * 20u + c3 : kInvalid;
-            }
-            wave_sync();
-        } else {
-            // ---- DNA: stage 215 bases, derive codon codes for both strands, then 4-codon half codes
-            const uint32_t ts = j * kDnaPosPerBlock;
-            const uint32_t nload = min(215u, L - ts);
-            for (uint32_t q = lane; q < 232; q += 64) {
-                uint32_t c = q < nload ? seq[soff + ts + q] : (uint32_t)'N';
-                ld.bc[q] = (uint8_t)dna_code(c);
-            }
-            wave_sync();
-            for (uint32_t q = lane; q < 213; q += 64) {
-                uint32_t b0 = ld.bc[q], b1 = ld.bc[q + 1], b2 = ld.bc[q + 2];
-                bool ok = (b0 < 4) & (b1 < 4) & (b2 < 4);
-                // translate (KGJ:320-343): codon index c1*16+c2*4+c3; non-ACGTU -> 'x' -> code 20
-                uint32_t f = (ld.t16[(b0 * 4 + b1) & 15] >> ((b2 & 3) * 5)) & 31u;
-                // reverse strand (KGJ:263-272 + 320-343): codon = compl(b2) compl(b1) compl(b0); compl code = 3 - code
-                uint32_t r = (ld.t16[((3 - b2) * 4 + (3 - b1)) & 15] >> (((3 - b0) & 3) * 5)) & 31u;
-                ld.F[q] = (uint8_t)(ok ? f : 20u);
-                ld.R[q] = (uint8_t)(ok ? r : 20u);
-            }
-            wave_sync();
-            for (uint32_t q = lane; q < 204; q += 64) {
-                uint32_t f0 = ld.F[q], f1 = ld.F[q + 3], f2 = ld.F[q + 6], f3 = ld.F[q + 9];
-                uint32_t r0 = ld.R[q], r1 = ld.R[q + 3], r2 = ld.R[q + 6], r3 = ld.R[q + 9];
-                bool okf = (f0 < 20) & (f1 < 20) & (f2 < 20) & (f3 < 20);
-                bool okr = (r0 < 20) & (r1 < 20) & (r2 < 20) & (r3 < 20);
-                ld.H[q] = okf ? f0 * 8000u + f1 * 400u + f2 * 20u + f3 : kInvalid;
-                // on the '-' strand the codon over the highest bases comes first
-                ld.G[q] = okr ? r3 * 8000u + r2 * 400u + r1 * 20u + r0 : kInvalid;
-            }
-            wave_sync();
-        }
-
-        const uint32_t vbase = 6u * bd.ibase;
         for (int g = 0; g < NG; g++) {
-            // ---- encodedKmer (KGJ:274-292) of this group's rows out of the half codes
             uint64_t val[RPG];
             bool valid[RPG];
 #pragma unroll
-            for (int q = 0; q < RPG; q++) {
-                if (AA) {
-                    uint32_t hi = la.H4[lane], lo = la.H4[lane + 4];
-                    uint32_t i = j * kAaWinPerBlock + lane;
-                    valid[q] = (hi != kInvalid) & (lo != kInvalid) & ((uint64_t)i + 8 < (uint64_t)L);
-                    val[q] = (uint64_t)hi * 160000ull + lo;
-                } else {
-                    const int r = g * RPG + q;                 // wave-uniform row: strand r/3, phase r%3
-                    const bool minus = r >= 3;
-                    const uint32_t pl = 3u * lane + (uint32_t)(minus ? r - 3 : r);
-                    const uint32_t *hc = minus ? ld.G : ld.H;
-                    uint32_t a = hc[pl], b = hc[pl + 12];
-                    valid[q] = (a != kInvalid) & (b != kInvalid);
-                    // '+': first four codons are the high half; '-': the codons over the higher bases are
-                    val[q] = minus ? (uint64_t)b * 160000ull + a : (uint64_t)a * 160000ull + b;
-                }
-            }
+            for (int q = 0; q < RPG; q++) valid[q] = row_value<AA>(l, g * RPG + q, lane, bd, &val[q]);
 
-            // ---- probe: home slot, 16 tags per load, records touched only on a fingerprint match
-            uint64_t cand[RPG];     // slot under examination
-            uint32_t fp[RPG], skip[RPG];
-            Tags16 tg[RPG];
-            uint64_t home[COUNTERS ? RPG : 1];
-#pragma unroll
-            for (int q = 0; q < RPG; q++) {
-                cand[q] = home_slot(val[q], tab);
-                fp[q] = tag_of(val[q]);
-                if (COUNTERS) { home[q] = cand[q]; if (valid[q]) ctr_valid++; }   // query k-mers (KGJ:913-920)
-                valid[q] = valid[q] && cand[q] < tab.limit;     // beyond the stream: EOF, not found, nothing inspected
-                cand[q] = probe_window(cand[q], &skip[q]);
-                if (valid[q]) tg[q] = load_tags(tab.tags + cand[q]);
-            }
-            // state per row: resolved, candidate at cand[q] (bit in st1), or keep walking from cand[q] (bit in pend)
-            uint32_t st1 = 0, pend = 0;
-            uint64_t stop[COUNTERS ? RPG : 1];
-#pragma unroll
-            for (int q = 0; q < RPG; q++) {
-                if (COUNTERS) stop[q] = cand[q];
-                if (valid[q]) {
-                    bool emp;
-                    int i = first_stop(tg[q], fp[q], &emp, skip[q]);
-                    if (i == 16) { pend |= 1u << q; cand[q] += 16; }
-                    else {
-                        cand[q] += (uint64_t)i;
-                        if (COUNTERS) stop[q] = cand[q];
-                        if (!emp) st1 |= 1u << q;
-                    }
-                }
-            }
-            Payload ent[RPG];       // the 16 payload bytes of the matching record
-            uint32_t foundm = 0;
-            {
-                Entry full[RPG];
-#pragma unroll
-                for (int q = 0; q < RPG; q++)
-                    if (st1 & (1u << q)) full[q] = load_entry(tab, cand[q]);
-#pragma unroll
-                for (int q = 0; q < RPG; q++) {
-                    if (st1 & (1u << q)) {
-                        if (full[q].key == (int64_t)val[q]) foundm |= 1u << q;
-                        else { pend |= 1u << q; cand[q] += 1; }       // fingerprint collision: keep walking
-                    }
-                    ent[q].oI = full[q].oI; ent[q].avg = full[q].avg; ent[q].fI = full[q].fI; ent[q].wt = full[q].wt;
-                }
-            }
-            // rows that need the generic walk (KGJ:944-1034 semantics: forward until the k-mer, an empty slot or
-            // the end of the stream; never wrap).  Rare; one shared copy of the walk, rows picked by register muxes.
-            while (__ballot(pend != 0)) {
-                if (pend) {
-                    const int r = __builtin_ctz(pend);
-                    uint64_t v = val[0], s = cand[0];
-                    uint32_t f = fp[0];
-#pragma unroll
-                    for (int q = 1; q < RPG; q++)
-                        if (r == q) { v = val[q]; s = cand[q]; f = fp[q]; }
-                    bool done = false, hit = false;
-                    Entry e;
-                    e.key = 0; e.oI = e.avg = e.fI = 0; e.wt = 0.f;
-                    if (s >= tab.limit) { done = true; s = tab.limit; }
-                    else {
-                        Tags16 x = load_tags(tab.tags + s);
-                        bool emp;
-                        int i = first_stop(x, f, &emp);
-                        if (i == 16) s += 16;
-                        else if (emp) { done = true; s += (uint64_t)i; }
-                        else {
-                            s += (uint64_t)i;
-                            e = load_entry(tab, s);
-                            if (e.key == (int64_t)v) done = hit = true;
-                            else s += 1;
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < RPG; q++) {
-                        if (r == q) {
-                            cand[q] = s;
-                            if (done) {
-                                if (COUNTERS) stop[q] = s;
-                                if (hit) { ent[q].oI = e.oI; ent[q].avg = e.avg; ent[q].fI = e.fI; ent[q].wt = e.wt; foundm |= 1u << q; }
-                            }
-                        }
-                    }
-                    if (done) pend &= pend - 1;
-                }
-            }
-            if (COUNTERS) {
-#pragma unroll
-                for (int q = 0; q < RPG; q++) {
-                    if (valid[q]) {
-                        uint64_t last = stop[q] < tab.limit ? stop[q] + 1 : tab.limit;
-                        ctr_slots += last - home[q];
-                    }
-                }
-            }
+            Payload ent[RPG];
+            const uint32_t foundm = probe_n<RPG, COUNTERS>(tab, val, valid, ent, ctr_valid, ctr_slots);
 
             // ---- ordered compaction: ballot per row, staging records handed out from the wave's reservation
             uint32_t cnt[RPG], rank[RPG];
@@ -428,12 +505,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
                 unsigned long long above = lane == 63 ? 0ull : (m >> (lane + 1));
                 rank[q] = (!AA && r >= 3) ? (uint32_t)__popcll(above) : (uint32_t)__popcll(below);
                 total += cnt[q];
-                // hits per (container, block) in container-major order: rows of one container are contiguous
-                uint32_t vrow;
-                if (AA) vrow = it;
-                else if (r < 3) vrow = vbase + (uint32_t)r * nk + j;
-                else vrow = vbase + (3u + (L - (uint32_t)(r - 3)) % 3u) * nk + (nk - 1u - j);
-                if (lane == 0) counts[vrow] = cnt[q];
+                if (lane == 0) counts[row_index<AA>(bd, it, r)] = cnt[q];
             }
             if (total > res_end - res_at) {                      // uniform: take a new chunk
                 unsigned long long chunk = total > stage_chunk ? total : stage_chunk;
@@ -450,24 +522,9 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
                 uint32_t rowbase = 0;
 #pragma unroll
                 for (int q = 0; q < RPG; q++) {
-                    const int r = g * RPG + q;
                     if ((foundm >> q) & 1u) {
                         kg_hit h;
-                        if (AA) {
-                            h.container = bd.seq;
-                            h.from0InProt = (int32_t)(j * kAaWinPerBlock + lane);
-                        } else if (r < 3) {
-                            // '+' strand: frame r (block start is a multiple of 3), residue index 64j + lane
-                            h.container = bd.seq * 6u + (uint32_t)r;
-                            h.from0InProt = (int32_t)(j * 64u + lane);
-                        } else {
-                            // '-' strand: the window over forward bases p..p+23 starts at reverse-complement base
-                            // b' = L-24-p, i.e. frame b'%3, residue b'/3 (KGJ:1068-1072).  24 % 3 == 0 and the
-                            // block start is a multiple of 3, so the frame depends on the row only.
-                            const uint32_t f = (uint32_t)(r - 3);
-                            h.container = bd.seq * 6u + 3u + (L - f) % 3u;
-                            h.from0InProt = (int32_t)((L - 24u - f - j * kDnaPosPerBlock) / 3u) - (int32_t)lane;
-                        }
+                        row_record_key<AA>(bd, g * RPG + q, lane, &h.container, &h.from0InProt);
                         h.oI = ent[q].oI; h.avgOffFromEnd = ent[q].avg; h.fI = ent[q].fI; h.functionWt = ent[q].wt;
                         stage[base + rowbase + rank[q]] = h;
                     }
@@ -478,17 +535,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
         wave_sync();   // LDS is reused by the next block
     }
 
-    if (COUNTERS) {
-        // wave reduction, one atomic pair per wave
-        for (int off = 32; off > 0; off >>= 1) {
-            ctr_valid += __shfl_down(ctr_valid, off);
-            ctr_slots += __shfl_down(ctr_slots, off);
-        }
-        if (lane == 0) {
-            atomicAdd(&ctr[0], ctr_valid);
-            atomicAdd(&ctr[1], ctr_slots);
-        }
-    }
+    if (COUNTERS) flush_counters(ctr_valid, ctr_slots, ctr, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -628,10 +675,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void place_kernel(const BlockDe
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         if ((uint32_t)r % rpg == 0) src = block_stage_base[(uint64_t)it * ng + (uint32_t)r / rpg];
-        uint32_t vrow;
-        if (AA) vrow = it;
-        else if (r < 3) vrow = 6u * bd.ibase + (uint32_t)r * bd.nk + bd.j;
-        else vrow = 6u * bd.ibase + (3u + (bd.len - (uint32_t)(r - 3)) % 3u) * bd.nk + (bd.nk - 1u - bd.j);
+        const uint32_t vrow = row_index<AA>(bd, it, r);
         uint32_t n = counts[vrow];
         if ((uint32_t)lane < n) hits[(uint64_t)offs[vrow] + lane] = stage[(uint64_t)src + lane];
         src += n;

@@ -7,6 +7,7 @@
 // scans reuse the same HBM.
 #include "kg_device.hpp"
 #include "kg_aggregate.hpp"
+#include "kg_partition.hpp"
 
 #include <cerrno>
 #include <cstdio>
@@ -132,8 +133,9 @@ uint32_t env_u32(const char *name, uint32_t dflt)
 {
     const char *v = getenv(name);
     if (!v || !*v) return dflt;
-    long x = strtol(v, nullptr, 10);
-    return x > 0 ? (uint32_t)x : dflt;
+    char *end = nullptr;
+    long x = strtol(v, &end, 10);
+    return (end != v && x >= 0) ? (uint32_t)x : dflt;
 }
 
 int dalloc(kg_table *t, void **p, size_t bytes)
@@ -457,6 +459,110 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         HIP_TRY(hipGetLastError());
     }
 
+    // ---- strategy: direct probing (every probe a random 128-byte line from HBM unless the tag array is
+    //      L2-sized) or partitioned probing (queries bucketed by slot range first; kg_partition.hpp) ----
+    uint64_t n_hits = 0;
+    st.scan_launches = 0;
+    uint32_t part_shift = 0, part_buckets = 0;
+    bool use_part = false;
+    {
+        // bucket = 2^shift slots (= bytes of tags); at most kMaxBuckets buckets; quotient must fit 32 - shift bits
+        uint32_t shift = env_u32("KG_PART_SHIFT", 21u);
+        while (((t->limit + (1ull << shift) - 1) >> shift) > (uint64_t)kg::kMaxBuckets) shift++;
+        const uint64_t qmax = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1;
+        const bool fits = shift < 32 && qmax < (1ull << (32 - shift)) && nblocks <= (1ull << 23);
+        // Measured at 1 Gbp x 33.6 GB table (profiles/r01_partition_path.md): direct 31 ms; partitioned 57 ms
+        // (count 15.6 + scatter 26.9 + probe 14.7): the L2-resident probe is 2x faster, but encoding twice and
+        // the scatter pass cost more than it saves.  So: opt-in only (KG_PARTITION=1), parity-tested either way.
+        const uint32_t mode = env_u32("KG_PARTITION", 0u);       // 0 direct probing (default), 1 partitioned whenever possible
+        use_part = fits && nblocks > 0 && mode == 1;
+        part_shift = shift;
+        part_buckets = (uint32_t)((t->limit + (1ull << shift) - 1) >> shift);
+    }
+    if (use_part) {
+        const uint32_t part_grid = env_u32("KG_PART_GRID", 256u * 5u);       // single-wave workgroups, ~5 per CU (LDS)
+        const uint32_t n_waves = part_grid;
+        uint32_t *d_M = nullptr, *d_tot = nullptr, *d_bstart = nullptr;
+        if ((rc = sc.get(&d_M, (size_t)part_buckets * n_waves))) return rc;
+        if ((rc = sc.get(&d_tot, (size_t)part_buckets + 8))) return rc;
+        if ((rc = sc.get(&d_bstart, (size_t)part_buckets + 8))) return rc;
+        unsigned long long *d_cursor = (unsigned long long *)(d_totals + 1);
+        unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
+        HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
+        HIP_TRY(hipEventRecord(t->ev[1], t->stream));
+        const dim3 pg(part_grid), pb(kg::kWave);
+        hipLaunchKernelGGL((kg::part_kernel<AA, false>), pg, pb, kg::part_lds_bytes<AA>(false, part_buckets), t->stream, d_seq, d_blocks, (uint32_t)nblocks, t->limit,
+                           (uint64_t)t->num_sigs, t->magic, part_shift, part_buckets, d_M, (const uint32_t *)nullptr,
+                           (uint64_t *)nullptr, d_ctr);
+        hipLaunchKernelGGL(kg::part_offsets_kernel, dim3(part_buckets), dim3(256), 0, t->stream, d_M, n_waves, d_tot);
+        hipLaunchKernelGGL(kg::part_bstart_kernel, dim3(1), dim3(256), 0, t->stream, d_tot, part_buckets, d_bstart, d_totals + 5);
+        HIP_TRY(hipGetLastError());
+        uint64_t h_ent = 0;
+        HIP_TRY(hipMemcpyAsync(&h_ent, d_totals + 5, 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        uint64_t *d_ent = nullptr;
+        if ((rc = sc.get(&d_ent, (size_t)h_ent + 4))) return rc;
+        hipLaunchKernelGGL((kg::part_kernel<AA, true>), pg, pb, kg::part_lds_bytes<AA>(true, part_buckets), t->stream, d_seq, d_blocks, (uint32_t)nblocks, t->limit,
+                           (uint64_t)t->num_sigs, t->magic, part_shift, part_buckets, d_M, d_bstart, d_ent, d_ctr);
+        HIP_TRY(hipGetLastError());
+        unsigned long long *d_masks = nullptr;
+        uint32_t *d_next = nullptr;
+        if ((rc = sc.get(&d_masks, (size_t)n_rows))) return rc;
+        if ((rc = sc.get(&d_next, (size_t)part_buckets + 8))) return rc;
+        HIP_TRY(hipMemsetAsync(d_masks, 0, n_rows * 8, t->stream));
+        const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 4u) & ~7u;
+        uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio) + (uint64_t)probe_grid * 4 * kg::kUChunk + 4096 +
+                         kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
+        kg_hit *d_ulist = nullptr;
+        uint32_t *d_cused = nullptr;
+        uint64_t n_chunks = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            if ((rc = dalloc(t, (void **)&d_ulist, ucap * sizeof(kg_hit)))) return rc;
+            if ((rc = dalloc(t, (void **)&d_cused, (ucap / kg::kUChunk + 1) * 4))) { sc.adopt(d_ulist); return rc; }
+            HIP_TRY(hipMemsetAsync(d_cused, 0, (ucap / kg::kUChunk + 1) * 4, t->stream));
+            HIP_TRY(hipMemsetAsync(d_cursor, 0, 8, t->stream));
+            HIP_TRY(hipMemsetAsync(d_totals + 3, 0, 8, t->stream));      // slots_inspected of a re-run starts over
+            HIP_TRY(hipMemsetAsync(d_next, 0, ((size_t)part_buckets + 8) * 4, t->stream));
+            if (counters)
+                hipLaunchKernelGGL((kg::bucket_probe_kernel<AA, true>), dim3(probe_grid), dim3(256), 0, t->stream, t->d_entries,
+                                   t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic, d_ent, d_bstart, part_buckets, part_shift,
+                                   d_next, d_ulist, d_cused, d_cursor, ucap, d_masks, d_ctr);
+            else
+                hipLaunchKernelGGL((kg::bucket_probe_kernel<AA, false>), dim3(probe_grid), dim3(256), 0, t->stream, t->d_entries,
+                                   t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic, d_ent, d_bstart, part_buckets, part_shift,
+                                   d_next, d_ulist, d_cused, d_cursor, ucap, d_masks, d_ctr);
+            HIP_TRY(hipGetLastError());
+            st.scan_launches++;
+            uint64_t h_cur = 0;
+            HIP_TRY(hipMemcpyAsync(&h_cur, d_cursor, 8, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            n_chunks = h_cur / kg::kUChunk;
+            if (h_cur <= ucap) break;
+            dfree(t, d_ulist); dfree(t, d_cused); d_ulist = nullptr; d_cused = nullptr;       // stream is idle here
+            if (attempt == 1) return fail(KG_ERR_DEVICE, "hit list overflow after resize (internal error)");
+            ucap = h_cur;                 // masks are idempotent (atomicOr): the re-run sets the same bits
+        }
+        sc.adopt(d_ulist); sc.adopt(d_cused);
+        HIP_TRY(hipEventRecord(t->ev[2], t->stream));
+        hipLaunchKernelGGL((kg::rows_from_masks_kernel<AA>), dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, t->stream,
+                           d_blocks, (uint32_t)nblocks, d_masks, d_counts);
+        if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) return rc;
+        uint64_t h_tot[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 32, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        n_hits = h_tot[0];
+        st.windows_valid = counters ? (int64_t)h_tot[2] : -1;
+        st.slots_inspected = counters ? (int64_t)h_tot[3] : -1;
+        if (windows) {
+            double ratio = (double)n_hits / (double)windows * 1.1 + 1e-3;
+            if (ratio > t->stage_ratio) t->stage_ratio = ratio > 1.0 ? 1.0 : ratio;
+        }
+        st.n_hits = (int64_t)n_hits;
+        if ((rc = dalloc(t, (void **)&res->d_hits, n_hits * sizeof(kg_hit)))) return rc;
+        if (n_chunks)
+            hipLaunchKernelGGL((kg::place_unordered_kernel<AA>), dim3((uint32_t)n_chunks), dim3(256), 0, t->stream, d_blocks,
+                               d_masks, d_offs, d_ulist, d_cused, (uint32_t)n_chunks, res->d_hits);
+    } else {
     // ---- scan: encode + probe + staged compaction; re-run once if the staging area was too small ----
     // persistent grid: enough workgroups to fill 256 CUs, few enough that per-wave staging chunks stay small
     const uint32_t scan_grid = env_u32("KG_SCAN_GRID", 256u * 8u);
@@ -468,8 +574,6 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                          (uint64_t)scan_grid * kg::kWavesPerWG * stage_chunk;
     if (stage_cap > 0xFFFFFF00ull) stage_cap = 0xFFFFFF00ull;
     kg_hit *d_stage = nullptr;
-    uint64_t n_hits = 0;
-    st.scan_launches = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = dalloc(t, (void **)&d_stage, stage_cap * sizeof(kg_hit)))) return rc;
         unsigned long long *d_cursor = (unsigned long long *)(d_totals + 1);
@@ -527,6 +631,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         uint32_t grid = (uint32_t)((nblocks + kg::kWavesPerWG - 1) / kg::kWavesPerWG);
         hipLaunchKernelGGL((kg::place_kernel<AA>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, t->stream, d_blocks,
                            (uint32_t)nblocks, d_counts, d_offs, d_bsb, rpg, d_stage, res->d_hits);
+    }
     }
     hipLaunchKernelGGL((kg::container_starts_kernel<AA>), dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream,
                        d_ibase, (uint32_t)n_seqs, d_offs, n_rows, d_totals, res->d_chs);

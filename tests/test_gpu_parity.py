@@ -12,6 +12,14 @@ from helpers import assert_same_records, plant
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["direct", "partitioned"])
+def strategy(request, monkeypatch):
+    """Every parity test runs with both scan strategies: direct probing and partitioned probing
+    (KG_PARTITION=1 forces the bucketed path even on tables small enough for the direct one)."""
+    monkeypatch.setenv("KG_PARTITION", "1" if request.param == "partitioned" else "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def hp():
     from kmergutsjava_amd import hotpath

@@ -15,15 +15,11 @@ tab = hotpath.SignatureTable.from_device_ptr(rec.data_ptr(), num_sigs, 0, keepal
 lens = synth.contig_mix_lengths(total_bp, 301); off = synth.offsets_of(lens)
 seq = synth.random_dna(int(off[-1]), 302, dev)
 torch.cuda.synchronize()
-variants = []
-for rpg in (1, 2, 3, 6):
-    variants.append(dict(KG_SCAN_RPG=rpg, KG_STAGE_CHUNK=512, KG_SCAN_GRID=2048))
-for chunk in (1, 64):
-    variants.append(dict(KG_SCAN_RPG=3, KG_STAGE_CHUNK=chunk, KG_SCAN_GRID=2048))
-for grid in (1024, 4096, 16384):
-    variants.append(dict(KG_SCAN_RPG=3, KG_STAGE_CHUNK=512, KG_SCAN_GRID=grid))
-for rpg, grid in ((2, 4096), (1, 4096), (2, 1024)):
-    variants.append(dict(KG_SCAN_RPG=rpg, KG_STAGE_CHUNK=512, KG_SCAN_GRID=grid))
+variants = [dict(KG_PARTITION=0)]
+for shift in (20, 21, 22):
+    variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=shift, KG_PART_GRID=1024, KG_PROBE_GRID=1024))
+for pg, qg in ((512, 1024), (1536, 1024), (1024, 512), (1024, 2048)):
+    variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=21, KG_PART_GRID=pg, KG_PROBE_GRID=qg))
 ref = None
 for v in variants:
     for k, x in v.items():
