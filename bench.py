@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--load", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bp", type=int, default=10_000_000)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
+                                                      "rehearsing the multi-rank path on a one-GPU box)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -54,10 +56,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if "KG_BENCH_DEVICE" in os.environ:               # rehearsal: several ranks share one GPU (gloo only)
+        local_rank = int(os.environ["KG_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- synthetic table (replicated) and this rank's contig shard, generated in HBM ----
     t0 = time.time()
@@ -75,13 +83,13 @@ def main():
     log("[bench] rank %d: %d contigs, %d bp" % (rank, len(lens), int(off[-1])))
 
     params = hotpath.Params()                      # reference defaults: -m 5 -g 200
-    gather_dev = dev
+    gather_dev = comm_dev
 
     def step():
         with tab.scan(None, off, params, device_ptr=seq.data_ptr()) as r:
             st = r.stats
             if world > 1:
-                local = {"calls": r.calls(), "container_call_start": r.container_call_start(), "otu": r.otu()}
+                local = {"calls": r.calls(), "otu": r.otu()}
                 kd.gather_records(local, np.arange(len(lens)) * world + rank, len(lens) * world, 6, gather_dev)
             else:
                 r.calls(); r.otu()                 # the records the report needs leave HBM
@@ -116,7 +124,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t1
 
-    tot = torch.tensor([elapsed, float(residues), float(hits)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([elapsed, float(residues), float(hits)], dtype=torch.float64, device=comm_dev)
     if world > 1:
         mx = tot[:1].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot[1:].clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
@@ -154,7 +162,7 @@ def main():
                        "parallelism": "contig shards x%d, table replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "kg::scan_kernel<false,false>", "kernel_ms": ms_scan,
+                         "kernel": "kg::scan_kernel<false,false,3>", "kernel_ms": ms_scan,
                          "alg_bytes_per_residue": b_alg, "slots_per_residue": p_bar, "hits_per_residue": h_bar,
                          "residues_per_launch": int(residues)},
             "stage_ms": {"scan": ms_scan, "order": float(np.mean(order_ms)), "aggregate": float(np.mean(agg_ms)),

@@ -60,54 +60,59 @@ def _gather_var(t: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
     return [b[:s] for b, s in zip(bufs, sizes)]
 
 
+def _restore(recs_by_rank, idx_by_rank, n_total_seqs: int, per: int, dtype):
+    """Concatenate per-rank records (container ids local to the rank's shard, grouped by container in
+    ascending order) into global container order.  Vectorised: no per-sequence Python loop."""
+    n_cont = n_total_seqs * per
+    gcont, recs = [], []
+    for r, rec in enumerate(recs_by_rank):
+        if len(rec) == 0:
+            continue
+        lc = rec["container"].astype(np.int64)
+        gcont.append(idx_by_rank[r][lc // per] * per + lc % per)
+        recs.append(rec)
+    starts = np.zeros(n_cont + 1, dtype=np.int64)
+    if not recs:
+        return np.zeros(0, dtype=dtype), starts
+    gcont = np.concatenate(gcont)
+    rec = np.concatenate(recs)
+    order = np.argsort(gcont, kind="stable")          # stable: keeps the emission order inside a container
+    rec = rec[order]
+    rec["container"] = gcont[order].astype(np.uint32)
+    np.cumsum(np.bincount(gcont, minlength=n_cont), out=starts[1:])
+    return rec, starts
+
+
 def gather_records(local: dict, shard_idx: np.ndarray, n_total_seqs: int, per: int, device=None) -> Optional[dict]:
     """Gather per-rank results to rank 0 and restore the original sequence order.
 
-    local: {"calls": CALL records, "container_call_start": int64[n_local*per+1], "otu": OTU records,
-            optional "hits" + "container_hit_start"} as numpy arrays, container ids local to the shard.
-    Returns on rank 0 the same dict in global numbering, None elsewhere."""
+    local: {"calls": CALL records, "otu": OTU records (one per local sequence), optional "hits"} as numpy
+    arrays with container ids local to the shard (container // per = local sequence index).
+    Returns on rank 0 {"calls", "container_call_start", "otu" [, "hits", "container_hit_start"]} in global
+    numbering, None elsewhere."""
     from . import _native as N
     device = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
 
     def tobytes(a: np.ndarray) -> torch.Tensor:
         return torch.from_numpy(np.frombuffer(np.ascontiguousarray(a).tobytes(), dtype=np.uint8).copy()).to(device)
 
-    names = ["calls", "container_call_start", "otu"] + (["hits", "container_hit_start"] if "hits" in local else [])
+    names = ["calls", "otu"] + (["hits"] if "hits" in local else [])
     parts = {"idx": _gather_var(tobytes(np.asarray(shard_idx, dtype=np.int64)))}
     for nm in names:
         parts[nm] = _gather_var(tobytes(local[nm]))
     if dist.get_rank() != 0:
         return None
-    dt = {"calls": N.CALL_DTYPE, "otu": N.OTU_DTYPE, "hits": N.HIT_DTYPE,
-          "container_call_start": np.dtype("<i8"), "container_hit_start": np.dtype("<i8"), "idx": np.dtype("<i8")}
+    dt = {"calls": N.CALL_DTYPE, "otu": N.OTU_DTYPE, "hits": N.HIT_DTYPE, "idx": np.dtype("<i8")}
     world = dist.get_world_size()
-    dec = {nm: [np.frombuffer(parts[nm][r].cpu().numpy().tobytes(), dtype=dt[nm]) for r in range(world)]
-           for nm in parts}
+    dec = {nm: [np.frombuffer(parts[nm][r].cpu().numpy().tobytes(), dtype=dt[nm]) for r in range(world)] for nm in parts}
     otu = np.zeros(n_total_seqs, dtype=N.OTU_DTYPE)
-    owner = np.full(n_total_seqs, -1, dtype=np.int64)
-    local_of = np.zeros(n_total_seqs, dtype=np.int64)
+    seen = np.zeros(n_total_seqs, dtype=np.int64)
     for r in range(world):
-        idx = dec["idx"][r]
-        owner[idx] = r
-        local_of[idx] = np.arange(len(idx))
-        otu[idx] = dec["otu"][r]
-    assert (owner >= 0).all(), "every sequence must belong to exactly one rank"
+        otu[dec["idx"][r]] = dec["otu"][r]
+        seen[dec["idx"][r]] += 1
+    assert (seen == 1).all(), "every sequence must belong to exactly one rank"
     out = {"otu": otu}
-    for rec, st in (("calls", "container_call_start"),) + ((("hits", "container_hit_start"),) if "hits" in local else ()):
-        chunks, starts = [], np.zeros(n_total_seqs * per + 1, dtype=np.int64)
-        at = 0
-        for s in range(n_total_seqs):
-            r, ls = int(owner[s]), int(local_of[s])
-            cs = dec[st][r]
-            for f in range(per):
-                a, b = int(cs[ls * per + f]), int(cs[ls * per + f + 1])
-                starts[s * per + f] = at
-                if b > a:
-                    c = dec[rec][r][a:b].copy()
-                    c["container"] = s * per + f
-                    chunks.append(c)
-                    at += b - a
-        starts[-1] = at
-        out[rec] = np.concatenate(chunks) if chunks else np.zeros(0, dtype=dt[rec])
-        out[st] = starts
+    out["calls"], out["container_call_start"] = _restore(dec["calls"], dec["idx"], n_total_seqs, per, N.CALL_DTYPE)
+    if "hits" in local:
+        out["hits"], out["container_hit_start"] = _restore(dec["hits"], dec["idx"], n_total_seqs, per, N.HIT_DTYPE)
     return out

@@ -39,7 +39,7 @@ def _worker(rank, world, port, dna, tmp):
         mine = shards[rank]
         s_seq, s_off = kd.take_shard(sb, off, mine)
         loc = kgo.run(img, s_seq, s_off, aa=not dna, lookup_mode=1)
-        local = {k: loc[k] for k in ("calls", "container_call_start", "otu", "hits", "container_hit_start")}
+        local = {k: loc[k] for k in ("calls", "otu", "hits")}
         got = kd.gather_records(local, mine, len(lens), per, device="cpu")
         if rank == 0:
             whole = kgo.run(img, sb, off, aa=not dna, lookup_mode=1)
