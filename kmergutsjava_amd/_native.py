@@ -100,11 +100,17 @@ def check(rc: int) -> None:
         raise KmerGutsNativeError(rc, load().kg_last_error().decode("utf-8", "replace"))
 
 
-def view(ptr: int, count: int, dtype: np.dtype) -> np.ndarray:
-    """Copy `count` records at `ptr` (library-owned host memory) into a fresh numpy array."""
+def view(ptr: int, count: int, dtype: np.dtype, owner=None) -> np.ndarray:
+    """`count` records at `ptr` (library-owned pinned host memory) as a numpy array.  With `owner` the array is a
+    zero-copy read-only view that keeps `owner` (the ScanResult) alive; without, a private copy."""
     if count == 0:
         return np.zeros(0, dtype=dtype)
     if not ptr:
         raise KmerGutsNativeError(-1, load().kg_last_error().decode("utf-8", "replace"))
     buf = (C.c_uint8 * (count * dtype.itemsize)).from_address(ptr)
-    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+    arr = np.frombuffer(buf, dtype=dtype, count=count)
+    if owner is None:
+        return arr.copy()
+    buf._owner = owner                      # the ctypes buffer is the array's base: keeps the result alive
+    arr.flags.writeable = False
+    return arr

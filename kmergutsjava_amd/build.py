@@ -42,5 +42,23 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+CLI = os.path.join(HERE, "kmer_guts")
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> str:
+    """The native command line (C++ over the C ABI): kmergutsjava_amd/kmer_guts."""
+    build_native(force, verbose)
+    src = os.path.join(CSRC, "kmer_guts_cli.cpp")
+    if force or _stale(CLI, [src, os.path.join(ROOT, "include", "kmerguts_hip.h")]):
+        cxx = shutil.which("g++") or shutil.which("hipcc")
+        cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-o", CLI, src, "-L" + HERE, "-lkmerguts_hip", "-lz",
+               "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv, verbose=True))
+    print(build_cli(force="--force" in sys.argv, verbose=True))

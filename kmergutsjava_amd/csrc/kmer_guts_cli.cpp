@@ -1,0 +1,396 @@
+// kmer_guts_cli.cpp -- native host front end of the hot path: the reference's command line
+// (KmerGutsJava.main, KGJ:560-654) and run() (KGJ:742-820) in C++ over the C ABI.
+//
+// "KGJ:n" = reference lib/src/kmergutsjava/KmerGutsJava.java line n.  The reference is compiled code (Java)
+// and the build image has no JDK, so the host side above libkmerguts_hip.so is C++ here (and Python in
+// kmer_guts_java.py; both produce the same bytes).  This file parses text and prints records; every number in
+// the report comes from the GPU through kg_scan.  There is no CPU fallback.
+//
+//   kmer_guts -D DataDir [-q query.fasta[.gz]] [-o out.txt] [-a] [-d] [-m minHits] [-M minWeightedHits] [-O] [-g maxGap]
+//
+// Same flags, same quirks: -t / -l fall into "Unknown parameter" (KGJ:605-611); after a parse error the usage
+// is printed and execution continues (KGJ:616-647); a missing -q is an error (new File(null), KGJ:647).
+// Differences: no "Processed: NN%" lines (the table is not streamed); -d prints the info lines only.
+#include <zlib.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/kmerguts_hip.h"
+
+namespace {
+
+struct Fatal { std::string msg; };
+
+[[noreturn]] void die(const std::string &m) { throw Fatal{m}; }
+
+// ---- file input (plain or .gz, KGJ:347-352, 764-769) ----
+std::vector<char> read_all(const std::string &path)
+{
+    std::vector<char> out;
+    const bool gz = path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    if (gz) {
+        gzFile f = gzopen(path.c_str(), "rb");
+        if (!f) die(path + " (No such file or directory)");
+        gzbuffer(f, 1 << 20);
+        std::vector<char> buf(8 << 20);
+        int n;
+        while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) out.insert(out.end(), buf.begin(), buf.begin() + n);
+        gzclose(f);
+        if (n < 0) die("error reading " + path);
+    } else {
+        FILE *f = path == "-" ? stdin : fopen(path.c_str(), "rb");
+        if (!f) die(path + " (No such file or directory)");
+        std::vector<char> buf(8 << 20);
+        size_t n;
+        while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) out.insert(out.end(), buf.begin(), buf.begin() + n);
+        if (f != stdin) fclose(f);
+    }
+    return out;
+}
+
+bool exists(const std::string &p)
+{
+    FILE *f = fopen(p.c_str(), "rb");
+    if (f) fclose(f);
+    return f != nullptr;
+}
+
+// ---- BufferedReader.readLine over a byte buffer: \n, \r or \r\n end a line ----
+struct Lines {
+    const char *p, *end;
+    bool next(const char *&b, const char *&e)
+    {
+        if (p >= end) return false;
+        b = p;
+        while (p < end && *p != '\n' && *p != '\r') p++;
+        e = p;
+        if (p < end) {
+            if (*p == '\r' && p + 1 < end && p[1] == '\n') p++;
+            p++;
+        }
+        return true;
+    }
+};
+
+// String.trim(): strips chars <= ' ' at both ends
+void trim(const char *&b, const char *&e)
+{
+    while (b < e && (unsigned char)*b <= ' ') b++;
+    while (e > b && (unsigned char)e[-1] <= ' ') e--;
+}
+
+// ---- loadIndexedArray (KGJ:345-369) ----
+std::vector<std::string> load_indexed_array(const std::vector<char> &text)
+{
+    std::vector<std::string> out;
+    Lines ln{text.data(), text.data() + text.size()};
+    const char *b, *e;
+    long pos = 0;
+    while (ln.next(b, e)) {
+        const char *tab = (const char *)memchr(b, '\t', (size_t)(e - b));
+        if (!tab) die("String index out of range: -1");
+        char *endp = nullptr;
+        std::string num(b, tab);
+        errno = 0;
+        long idx = strtol(num.c_str(), &endp, 10);
+        if (num.empty() || *endp || errno) die("For input string: \"" + num + "\"");
+        if (idx != pos) die("Your index must be dense and in order (see line " + std::to_string(pos) + ")");
+        out.emplace_back(tab + 1, e);
+        pos++;
+    }
+    return out;
+}
+
+// ---- readFasta (KGJ:1132-1192): id = first token after '>', sequence lines concatenated untrimmed ----
+struct Fasta {
+    std::vector<std::string> ids;
+    std::vector<uint8_t> seq;          // all sequences back to back
+    std::vector<int64_t> off{0};
+};
+
+void read_fasta(const std::vector<char> &text, Fasta &fa)
+{
+    Lines ln{text.data(), text.data() + text.size()};
+    const char *b = nullptr, *e = nullptr;
+    bool have = false;                  // str1 carried over from the previous record
+    fa.seq.reserve(text.size());
+    for (;;) {
+        std::string name;
+        bool got_name = false;
+        if (!have) have = ln.next(b, e);
+        while (have) {
+            const char *tb = b, *te = e;
+            trim(tb, te);
+            if (te - tb > 1) {
+                const char *rb = tb + 1, *re = te;
+                trim(rb, re);
+                if (*tb == '>' && re > rb) {
+                    // StringTokenizer(str2.substring(1), " \t").nextToken()
+                    const char *q = tb + 1;
+                    while (q < te && (*q == ' ' || *q == '\t')) q++;
+                    const char *q2 = q;
+                    while (q2 < te && *q2 != ' ' && *q2 != '\t') q2++;
+                    name.assign(q, q2);
+                    got_name = true;
+                    break;
+                }
+                die("Wrong caption line: " + std::string(tb, te));
+            }
+            have = ln.next(b, e);
+        }
+        if (!got_name) return;
+        for (;;) {
+            have = ln.next(b, e);
+            const char *tb = b, *te = e;
+            if (have) trim(tb, te);
+            if (!have || (te > tb && *tb == '>')) die("No sequence for caption: " + name);
+            if (te > tb) break;
+        }
+        const size_t start = fa.seq.size();
+        for (;;) {
+            fa.seq.insert(fa.seq.end(), (const uint8_t *)b, (const uint8_t *)e);     // untrimmed (KGJ:1176)
+            have = ln.next(b, e);
+            if (!have) break;
+            const char *tb = b, *te = e;
+            trim(tb, te);
+            if (te > tb && *tb == '>') break;
+        }
+        if (fa.seq.size() == start) die("No sequence for caption: " + name);
+        fa.ids.push_back(std::move(name));
+        fa.off.push_back((int64_t)fa.seq.size());
+    }
+}
+
+// ---- String.format("%f") of a float: decimal digits of (double)v rounded HALF_UP (java.util.Formatter) ----
+// For a float the only inputs on which HALF_UP and printf's round-half-even differ are exact ties,
+// i.e. v * 2^(p+1) an odd integer.
+int format_java_f(float v, int precision, char *buf, size_t bufsz)
+{
+    double d = (double)v;
+    if (std::isnan(d)) return snprintf(buf, bufsz, "NaN");
+    if (std::isinf(d)) return snprintf(buf, bufsz, d < 0 ? "-Infinity" : "Infinity");
+    double ad = std::fabs(d);
+    double scaled = std::ldexp(ad, precision + 1);
+    if (precision >= 0 && precision <= 9 && scaled < 9.0e15 && scaled == std::floor(scaled) && std::fmod(scaled, 2.0) == 1.0) {
+        uint64_t k = (uint64_t)scaled, p5 = 1, p10 = 1;
+        for (int i = 0; i < precision; i++) { p5 *= 5; p10 *= 10; }
+        if (k < UINT64_MAX / p5 - 1) {
+            uint64_t units = (k * p5 + 1) / 2;
+            return snprintf(buf, bufsz, "%s%llu.%0*llu", std::signbit(d) ? "-" : "", (unsigned long long)(units / p10), precision,
+                            (unsigned long long)(units % p10));
+        }
+    }
+    return snprintf(buf, bufsz, "%.*f", precision, d);
+}
+
+struct Options {
+    bool aa = false, order_constraint = false, debug = false;
+    int min_hits = 5, min_weighted_hits = 0, max_gap = 200;
+    bool has_dir = false, has_query = false, has_out = false;
+    std::string dir, query, out;
+};
+
+int parse_int(const char *s)
+{
+    if (!s) die("null");
+    char *endp = nullptr;
+    errno = 0;
+    long v = strtol(s, &endp, 10);
+    if (!*s || *endp || errno || v < INT32_MIN || v > INT32_MAX) die(std::string("For input string: \"") + s + "\"");
+    return (int)v;
+}
+
+const char *kUsage[] = {
+    "Usage: kmer_guts [options] -D DataDir",
+    "Arguments:",
+    " -a - (optional) amino acids in input FASTA (default is DNA)",
+    " -d - (optional) print debug messages",
+    " -m - (optional) min. number of hits in result (integer, default = 5)",
+    " -M - (optional) min. sum of hit weights (integer, default = 0)",
+    " -O - (optional) order constraint (don't use order by default)",
+    " -g - (optional) max. gap between hits to be joined (integer, default = 200)",
+    " -D - (required) data directory with kmer-table and function-index files",
+    " -q - (optional) query fasta file (STDIN if not defined)",
+    " -o - (optional) output file (STDOUT if not defined)",
+    " -t - (optional) temporary directory (system one is used by default)",
+    " -l - (optional) limit for input Kmer array (long, default = 20,000,000)",
+};
+
+void parse_args(int argc, char **argv, Options &o)
+{
+    int i = 1;
+    auto poll = [&]() -> const char * { return i < argc ? argv[i++] : nullptr; };
+    try {
+        while (i < argc) {
+            std::string param = argv[i++];
+            if (param.empty() || param[0] != '-') die("Parameter name should start from '-': " + param);
+            param = param.substr(1);
+            if (param.size() != 1) die("Unknown parameter: -" + param);
+            switch (param[0]) {
+            case 'a': o.aa = true; break;
+            case 'd': o.debug = true; break;
+            case 'm': o.min_hits = parse_int(poll()); break;
+            case 'M': o.min_weighted_hits = parse_int(poll()); break;
+            case 'O': o.order_constraint = true; break;
+            case 'g': o.max_gap = parse_int(poll()); break;
+            case 'D': { const char *v = poll(); o.has_dir = v != nullptr; if (v) o.dir = v; break; }
+            case 'q': { const char *v = poll(); o.has_query = v != nullptr; if (v) o.query = v; break; }
+            case 'o': { const char *v = poll(); o.has_out = v != nullptr; if (v) o.out = v; break; }
+            case 't': (void)poll();  /* falls through, KGJ:605-607 */
+            case 'l': { const char *v = poll(); if (!v) die("null"); (void)strtoll(v, nullptr, 10); }  /* falls through, KGJ:607-609 */
+            default: die("Unknown parameter: -" + param);
+            }
+        }
+        if (!o.has_dir) die("-D parameter is required");
+    } catch (const Fatal &f) {
+        printf("Error: %s\n", f.msg.c_str());
+        for (const char *l : kUsage) printf("%s\n", l);
+    }
+}
+
+struct Out {
+    FILE *f;
+    std::string buf;
+    void flush() { if (!buf.empty()) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); } fflush(f); }
+    void put(const std::string &s) { buf += s; if (buf.size() > (8u << 20)) flush(); }
+};
+
+void check(int rc)
+{
+    if (rc != KG_OK) die(std::string("libkmerguts_hip: ") + kg_last_error());
+}
+
+long long now_ms()
+{
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    Options o;
+    parse_args(argc, argv, o);
+    try {
+        if (!o.has_dir) die("kmerTableDir is null");
+        if (!o.has_query) die("queryFastaFile is null");          // KGJ:647: new File(null)
+        const bool to_stdout = !o.has_out;
+        Out out{to_stdout ? stdout : fopen(o.out.c_str(), "wb"), {}};
+        if (!out.f) die(o.out + " (cannot open for writing)");
+        auto info = [&](const std::string &m) {                    // printInfoLine, KGJ:891-898
+            if (o.debug) out.put(m + "\n");
+            if (!to_stdout) printf("%s\n", m.c_str());
+        };
+        const char *tmp = getenv("TMPDIR");
+        info(std::string("Temp. directory: ") + (tmp ? tmp : "/tmp"));
+
+        std::string table = o.dir + "/kmer.table.mem_map", fidx = o.dir + "/function.index";
+        if (exists(table + ".gz")) table += ".gz";                 // KGJ:750-753
+        if (exists(fidx + ".gz")) fidx += ".gz";
+        const std::vector<std::string> functions = load_indexed_array(read_all(fidx));
+
+        kg_table *tab = nullptr;
+        if (table.size() > 3 && table.compare(table.size() - 3, 3, ".gz") == 0) {
+            std::vector<char> img = read_all(table);
+            check(kg_table_from_memory(img.data(), img.size(), 0, &tab));
+        } else {
+            check(kg_table_open(table.c_str(), 0, &tab));
+        }
+
+        long long t1 = now_ms();
+        Fasta fa;
+        read_fasta(read_all(o.query), fa);
+        info("Preparation time: " + std::to_string(now_ms() - t1) + " ms.");
+
+        // queryIdToLen / hitCnts are maps (KGJ:772, 805-809): a repeated id is reported once, at the place of its
+        // first record, with the length and the hits of its last record
+        const int64_t n = (int64_t)fa.ids.size();
+        std::unordered_map<std::string, int64_t> last_of;
+        std::vector<int64_t> first_order;
+        for (int64_t k = 0; k < n; k++) {
+            auto it = last_of.find(fa.ids[(size_t)k]);
+            if (it == last_of.end()) { last_of.emplace(fa.ids[(size_t)k], k); first_order.push_back(k); }
+            else it->second = k;
+        }
+        std::vector<int64_t> order;
+        order.reserve(first_order.size());
+        for (int64_t k : first_order) order.push_back(last_of[fa.ids[(size_t)k]]);
+
+        long long t2 = now_ms();
+        kg_params p{};
+        p.aa = o.aa; p.order_constraint = o.order_constraint; p.min_hits = o.min_hits;
+        p.min_weighted_hits = o.min_weighted_hits; p.max_gap = o.max_gap; p.flags = 0;
+        const int per = o.aa ? 1 : 6;
+        const int64_t kMaxBatchChars = 1500000000ll;               // below the ABI's 2^32-256 windows per call
+        long long t_group = 0;
+        size_t at = 0;
+        char num[64];
+        while (at < order.size()) {
+            // one batch: the next records, in report order, gathered into one buffer
+            std::vector<uint8_t> bseq;
+            std::vector<int64_t> boff{0};
+            size_t end = at;
+            while (end < order.size()) {
+                const int64_t k = order[end];
+                const int64_t len = fa.off[(size_t)k + 1] - fa.off[(size_t)k];
+                if (end > at && boff.back() + len > kMaxBatchChars) break;
+                bseq.insert(bseq.end(), fa.seq.begin() + fa.off[(size_t)k], fa.seq.begin() + fa.off[(size_t)k + 1]);
+                boff.push_back(boff.back() + len);
+                end++;
+            }
+            kg_result *res = nullptr;
+            check(kg_scan(tab, &p, bseq.data(), boff.data(), (int64_t)(end - at), &res));
+            const kg_call *calls = kg_result_calls(res);
+            const int64_t *ccs = kg_result_container_call_start(res);
+            const kg_otu *otu = kg_result_otu(res);
+            if (!ccs || !otu) die(std::string("libkmerguts_hip: ") + kg_last_error());
+            // with one batch (inputs up to ~1.5 Gbp) the info lines sit exactly where the reference prints them
+            if (at == 0) info("Lookup time: " + std::to_string(now_ms() - t2) + " ms.");
+            long long t3 = now_ms();
+            for (size_t j = 0; j < end - at; j++) {
+                const std::string &id = fa.ids[(size_t)order[at + j]];
+                const long long len = (long long)(boff[j + 1] - boff[j]);
+                std::string r;
+                if (o.aa) r += "PROTEIN-ID\t" + id + "\t" + std::to_string(len) + "\n";              // KGJ:529
+                else r += "processing " + id + "[" + std::to_string(len) + "]\n";                    // KGJ:541
+                for (int f = 0; f < per; f++) {
+                    if (!o.aa)                                                                         // KGJ:545
+                        r += "TRANSLATION\t" + id + "\t" + std::to_string(len) + "\t" + (f < 3 ? "+" : "-") + "\t" +
+                             std::to_string(f % 3) + "\n";
+                    for (int64_t c = ccs[j * per + f]; c < ccs[j * per + f + 1]; c++) {               // KGJ:398-404
+                        const kg_call &cl = calls[c];
+                        if (cl.fI < 0 || (size_t)cl.fI >= functions.size())
+                            die("Index: " + std::to_string(cl.fI) + ", Size: " + std::to_string(functions.size()));
+                        format_java_f(cl.weightedHits, 6, num, sizeof num);
+                        r += "CALL\t" + std::to_string(cl.start) + "\t" + std::to_string(cl.end) + "\t" + std::to_string(cl.count) +
+                             "\t" + std::to_string(cl.fI) + "\t" + functions[(size_t)cl.fI] + "\t" + num + "\n";
+                    }
+                }
+                r += "OTU-COUNTS\t" + id + "[" + std::to_string(len) + "]";                          // KGJ:518-522
+                for (int k2 = 0; k2 < otu[j].n; k2++) r += "\t" + std::to_string(otu[j].count[k2]) + "-" + std::to_string(otu[j].oI[k2]);
+                r += "\n";
+                out.put(r);
+            }
+            t_group += now_ms() - t3;
+            kg_result_free(res);
+            at = end;
+        }
+        info("Grouping time: " + std::to_string(t_group) + " ms.");
+        out.flush();
+        if (!to_stdout) fclose(out.f);
+        kg_table_close(tab);
+    } catch (const Fatal &f) {
+        fprintf(stderr, "Exception: %s\n", f.msg.c_str());
+        return 1;
+    }
+    return 0;
+}

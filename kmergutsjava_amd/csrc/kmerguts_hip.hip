@@ -119,12 +119,8 @@ struct kg_result {
     kg_call *d_calls = nullptr;
     int64_t *d_ccs = nullptr;
     kg_otu *d_otu = nullptr;
-    // host copies (lazy)
-    std::vector<kg_hit> h_hits;
-    std::vector<int64_t> h_chs, h_ccs;
-    std::vector<kg_call> h_calls;
-    std::vector<kg_otu> h_otu;
-    bool have_hits = false, have_chs = false, have_calls = false, have_ccs = false, have_otu = false;
+    // host copies (lazy), in pinned memory so the copy runs at PCIe rate
+    void *h_hits = nullptr, *h_chs = nullptr, *h_ccs = nullptr, *h_calls = nullptr, *h_otu = nullptr;
 };
 
 namespace {
@@ -350,6 +346,8 @@ void kg_result_free(kg_result *r)
         // a result is only handed out after its scan has synchronised the stream
         dfree(t, r->d_hits); dfree(t, r->d_chs); dfree(t, r->d_calls); dfree(t, r->d_ccs); dfree(t, r->d_otu);
     }
+    for (void *h : {r->h_hits, r->h_chs, r->h_ccs, r->h_calls, r->h_otu})
+        if (h) (void)hipHostFree(h);
     delete r;
 }
 
@@ -728,20 +726,20 @@ int scan_entry(kg_table *t, const kg_params *p, const uint8_t *seq, bool on_devi
 }
 
 template <typename T>
-const T *host_view(kg_result *r, std::vector<T> &v, bool &have, const T *d, size_t n)
+const T *host_view(kg_result *r, void *&slot, const T *d, size_t n)
 {
-    if (have) return v.data();
+    if (slot) return (const T *)slot;
     if (!d && n) { g_err = "record kind not computed (KG_F_SKIP_AGGREGATE?)"; return nullptr; }
-    v.resize(n ? n : 1);
-    if (n) {
-        if (hipSetDevice(r->tab->device) != hipSuccess ||
-            hipMemcpy(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) {
-            g_err = "device to host copy failed";
-            return nullptr;
-        }
+    if (hipSetDevice(r->tab->device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+    void *h = nullptr;
+    if (hipHostMalloc(&h, n ? n * sizeof(T) : 64) != hipSuccess) { g_err = "pinned host allocation failed"; return nullptr; }
+    if (n && hipMemcpy(h, d, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipHostFree(h);
+        g_err = "device to host copy failed";
+        return nullptr;
     }
-    have = true;
-    return v.data();
+    slot = h;
+    return (const T *)h;
 }
 
 }  // namespace
@@ -768,27 +766,27 @@ int kg_result_stats(const kg_result *r, kg_stats *out)
 
 const kg_hit *kg_result_hits(kg_result *r)
 {
-    return r ? host_view(r, r->h_hits, r->have_hits, r->d_hits, (size_t)r->st.n_hits) : nullptr;
+    return r ? host_view(r, r->h_hits, r->d_hits, (size_t)r->st.n_hits) : nullptr;
 }
 const int64_t *kg_result_container_hit_start(kg_result *r)
 {
-    return r ? host_view(r, r->h_chs, r->have_chs, r->d_chs, (size_t)r->st.n_containers + 1) : nullptr;
+    return r ? host_view(r, r->h_chs, r->d_chs, (size_t)r->st.n_containers + 1) : nullptr;
 }
 const kg_call *kg_result_calls(kg_result *r)
 {
-    return r ? host_view(r, r->h_calls, r->have_calls, r->d_calls, (size_t)r->st.n_calls) : nullptr;
+    return r ? host_view(r, r->h_calls, r->d_calls, (size_t)r->st.n_calls) : nullptr;
 }
 const int64_t *kg_result_container_call_start(kg_result *r)
 {
     if (!r) return nullptr;
     if (!r->d_ccs) { g_err = "calls not computed (KG_F_SKIP_AGGREGATE)"; return nullptr; }
-    return host_view(r, r->h_ccs, r->have_ccs, r->d_ccs, (size_t)r->st.n_containers + 1);
+    return host_view(r, r->h_ccs, r->d_ccs, (size_t)r->st.n_containers + 1);
 }
 const kg_otu *kg_result_otu(kg_result *r)
 {
     if (!r) return nullptr;
     if (!r->d_otu) { g_err = "OTU votes not computed (KG_F_SKIP_AGGREGATE)"; return nullptr; }
-    return host_view(r, r->h_otu, r->have_otu, r->d_otu, (size_t)r->st.n_seqs);
+    return host_view(r, r->h_otu, r->d_otu, (size_t)r->st.n_seqs);
 }
 const void *kg_result_device_hits(const kg_result *r) { return r ? r->d_hits : nullptr; }
 const void *kg_result_device_calls(const kg_result *r) { return r ? r->d_calls : nullptr; }

@@ -47,9 +47,11 @@ class ScanResult:
             raise ValueError("ScanResult is closed")
         return N.load()
 
-    def hits(self) -> np.ndarray:
+    def hits(self, copy: bool = True) -> np.ndarray:
+        """Hit records ordered by (container, from0InProt).  copy=False: zero-copy view of the library's pinned
+        buffer, valid until close()."""
         lib = self._need()
-        return N.view(lib.kg_result_hits(self._h), self.stats["n_hits"], N.HIT_DTYPE)
+        return N.view(lib.kg_result_hits(self._h), self.stats["n_hits"], N.HIT_DTYPE, None if copy else self)
 
     def container_hit_start(self) -> np.ndarray:
         lib = self._need()

@@ -71,3 +71,10 @@ def test_hip_and_cli_reproduce_golden(idx, tmp_path):
             args += [flag, str(p[key])]
     KmerGutsJava.main(args)
     assert (tmp_path / "out.txt").read_text() == v["report"]
+    # the native front end (C++ over the same C ABI) prints the same bytes
+    import subprocess
+    from kmergutsjava_amd import build
+    cli = build.build_cli()
+    args[args.index("-o") + 1] = str(tmp_path / "out_cli.txt")
+    subprocess.run([cli] + args, check=True, stdout=subprocess.DEVNULL)
+    assert (tmp_path / "out_cli.txt").read_text() == v["report"]

@@ -318,3 +318,33 @@ def test_cli_gz_data_dir_and_duplicate_ids(tmp_path):
     got = (tmp_path / "o.txt").read_text()
     assert got == want
     assert got.count("processing ") == 3 and "CALL\t" in got
+
+
+def test_native_cli_equals_python_mirror_on_ecoli(tmp_path):
+    """kmer_guts (C++) and KmerGutsJava.main (Python) over the same data directory and the reference's E. coli
+    genome / proteome: identical report bytes, to stdout and to a file, gz and plain inputs, -a and DNA mode."""
+    import gzip, os, subprocess, sys, io
+    from kmergutsjava_amd import synth, build, KmerGutsJava
+    cli = build.build_cli()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ids_p, prot, off_p = _ecoli("Ecoli_K12_W3110.faa.gz")
+    codes = synth.aa_codes(torch.frombuffer(bytearray(prot), dtype=torch.uint8))
+    vals = synth.encode_windows_aa(codes)
+    vals = vals[vals >= 0]
+    keys = torch.unique(torch.cat([vals[synth._uniform(81, 0, 300000, int(vals.numel()), "cpu")], synth.random_keys(100000, 82)]))
+    fn = (synth._lsr(synth.splitmix64(83, keys // 20 ** 5), 3) % 300).to(torch.int32)
+    otu, avg, _, wt = synth.payload_of(keys, 84, n_otu=9)
+    rec, _ = synth.build_table(keys, (otu, avg, fn, wt), 1_000_003)
+    synth.write_data_dir(str(tmp_path / "d"), synth.table_image(rec), 300, gz=False)
+    for name, extra in (("Ecoli_K12_W3110.fna.gz", ["-m", "3"]), ("Ecoli_K12_W3110.faa.gz", ["-a", "-g", "100"])):
+        q = os.path.join(gold, name)
+        a, b = tmp_path / (name + ".py.txt"), tmp_path / (name + ".cli.txt")
+        KmerGutsJava.main(["-D", str(tmp_path / "d"), "-q", q, "-o", str(a)] + extra)
+        subprocess.run([cli, "-D", str(tmp_path / "d"), "-q", q, "-o", str(b)] + extra, check=True, stdout=subprocess.DEVNULL)
+        ta, tb = a.read_bytes(), b.read_bytes()
+        assert ta == tb and ta.count(b"CALL\t") > 10, name
+        so = subprocess.run([cli, "-D", str(tmp_path / "d"), "-q", q] + extra, check=True, stdout=subprocess.PIPE).stdout
+        assert so == ta
+    # flag quirks: -t falls through to "Unknown parameter" and parsing stops (KGJ:605-611, 616-636)
+    r = subprocess.run([cli, "-t", "/tmp", "5", "-D", str(tmp_path / "d")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert b"Error: Unknown parameter: -t" in r.stdout and b"Usage: kmer_guts" in r.stdout and r.returncode != 0

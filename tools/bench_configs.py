@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs 1, 2 and 5 through the C ABI (configs 3/4 are bench.py).  Parity-test cases, not bench
+lines: each is first checked against the CPU oracle at a size the oracle finishes in seconds, then timed."""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kmergutsjava_amd import hotpath, synth
+from oracle import kgo
+kgo.build()
+dev = torch.device("cuda", 0)
+out = {}
+
+def timed(tab, off, params, seq_dev, reps=4):
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        with tab.scan(None, off, params, device_ptr=seq_dev.data_ptr()) as r:
+            r.calls(); r.otu(); st = r.stats
+        w = time.perf_counter() - t0
+        if best is None or w < best[0]:
+            best = (w, st)
+    w, st = best
+    return {"ms_per_step": w * 1e3, "residues_per_s": st["residues"] / w, "hits_per_s": st["n_hits"] / w,
+            "calls_per_s": st["n_calls"] / w, "n_hits": st["n_hits"], "n_calls": st["n_calls"], "residues": st["residues"],
+            "stage_ms": {k: st[k] for k in ("ms_scan", "ms_order", "ms_aggregate", "ms_total")}}
+
+def check(tab, img, seq_dev, off, n_seqs, **kw):
+    sub_off = off[:n_seqs + 1]
+    sb = seq_dev[:int(sub_off[-1])].cpu().numpy()
+    ora = kgo.run(img, sb, sub_off, lookup_mode=1, **kw)
+    with tab.scan(sb, sub_off, hotpath.Params(**kw)) as r:
+        ok = (r.hits().tobytes() == ora["hits"].tobytes() and r.calls().tobytes() == ora["calls"].tobytes()
+              and r.otu().tobytes() == ora["otu"].tobytes())
+    return {"sequences_checked": n_seqs, "hits": len(ora["hits"]), "calls": len(ora["calls"]), "bit_identical": bool(ok)}
+
+# ---- config 1: 10 k proteins ~300 aa, 1 000 003-slot table, AA mode
+seq, off, rec, placed = synth.plumbing_config(10000, 1000003, 500000, dev)
+torch.cuda.synchronize()
+img = synth.table_image(rec)
+with hotpath.SignatureTable.from_bytes(img) as tab:
+    out["config1_plumbing_aa"] = dict(timed(tab, off, hotpath.Params(aa=True), seq), parity=check(tab, img, seq, off, 10000, aa=True))
+
+# ---- config 2: 1000 x 100 kbp uniform DNA vs the full table
+num_sigs = int(os.environ.get("SW_NUM_SIGS", "1400303159"))
+rec, placed, keys = synth.random_table(num_sigs, 0.5, 202, dev); del keys
+torch.cuda.synchronize()
+tab = hotpath.SignatureTable.from_device_ptr(rec.data_ptr(), num_sigs, 0, keepalive=rec)
+seq, off = synth.dna_uniform_config(1000, 100000, 201, dev)
+torch.cuda.synchronize()
+out["config2_100Mbp_full_table"] = timed(tab, off, hotpath.Params(), seq)
+tab.close(); del rec
+
+# ---- config 5: high hit density (sequences drawn from signature k-mers), DNA and protein
+for dna in (True, False):
+    n_contigs, kpc = (1000, 4167) if dna else (10000, 38)          # 100 Mbp of DNA / 10 k proteins of ~300 aa
+    seq, off, rec = synth.high_density_device(n_contigs, kpc, 20000003, 8000000, 501, dna, dev)
+    torch.cuda.synchronize()
+    img = synth.table_image(rec)
+    with hotpath.SignatureTable.from_bytes(img) as tab:
+        name = "config5_high_density_" + ("dna" if dna else "aa")
+        out[name] = dict(timed(tab, off, hotpath.Params(aa=not dna), seq),
+                         parity=check(tab, img, seq, off, 40 if dna else 2000, aa=not dna))
+print(json.dumps(out, indent=1))
