@@ -335,20 +335,28 @@ int main(int argc, char **argv)
         size_t at = 0;
         char num[64];
         while (at < order.size()) {
-            // one batch: the next records, in report order, gathered into one buffer
+            // one batch: the next records, in report order.  No repeated ids and everything in one batch (the
+            // usual case): scan the parsed buffer in place; otherwise gather the batch's records into one buffer.
             std::vector<uint8_t> bseq;
             std::vector<int64_t> boff{0};
             size_t end = at;
-            while (end < order.size()) {
-                const int64_t k = order[end];
-                const int64_t len = fa.off[(size_t)k + 1] - fa.off[(size_t)k];
-                if (end > at && boff.back() + len > kMaxBatchChars) break;
-                bseq.insert(bseq.end(), fa.seq.begin() + fa.off[(size_t)k], fa.seq.begin() + fa.off[(size_t)k + 1]);
-                boff.push_back(boff.back() + len);
-                end++;
+            const bool in_place = at == 0 && order.size() == (size_t)n && fa.off.back() <= kMaxBatchChars;
+            if (in_place) {
+                end = order.size();
+            } else {
+                while (end < order.size()) {
+                    const int64_t k = order[end];
+                    const int64_t len = fa.off[(size_t)k + 1] - fa.off[(size_t)k];
+                    if (end > at && boff.back() + len > kMaxBatchChars) break;
+                    bseq.insert(bseq.end(), fa.seq.begin() + fa.off[(size_t)k], fa.seq.begin() + fa.off[(size_t)k + 1]);
+                    boff.push_back(boff.back() + len);
+                    end++;
+                }
             }
+            const uint8_t *sptr = in_place ? fa.seq.data() : bseq.data();
+            const std::vector<int64_t> &boffr = in_place ? fa.off : boff;
             kg_result *res = nullptr;
-            check(kg_scan(tab, &p, bseq.data(), boff.data(), (int64_t)(end - at), &res));
+            check(kg_scan(tab, &p, sptr, boffr.data(), (int64_t)(end - at), &res));
             const kg_call *calls = kg_result_calls(res);
             const int64_t *ccs = kg_result_container_call_start(res);
             const kg_otu *otu = kg_result_otu(res);
@@ -358,7 +366,7 @@ int main(int argc, char **argv)
             long long t3 = now_ms();
             for (size_t j = 0; j < end - at; j++) {
                 const std::string &id = fa.ids[(size_t)order[at + j]];
-                const long long len = (long long)(boff[j + 1] - boff[j]);
+                const long long len = (long long)(boffr[j + 1] - boffr[j]);
                 std::string r;
                 if (o.aa) r += "PROTEIN-ID\t" + id + "\t" + std::to_string(len) + "\n";              // KGJ:529
                 else r += "processing " + id + "[" + std::to_string(len) + "]\n";                    // KGJ:541
