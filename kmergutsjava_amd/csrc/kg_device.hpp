@@ -214,20 +214,43 @@ __device__ __forceinline__ void encode_init(typename WaveLds<AA>::type &l, int l
     wave_sync();
 }
 
-// Stage one block's characters and leave the 4-residue half codes in LDS (all lanes of the wave).
+// The raw characters of one block, 4 per lane (lane q holds characters q, q+64, q+128, q+192 of the block's
+// window; AA blocks use the first two).  Separate from the encode step so that a caller can fetch the next
+// block's characters while it works on the current one.
 template <bool AA>
-__device__ __forceinline__ void encode_block(typename WaveLds<AA>::type &l, const uint8_t *__restrict__ seq,
-                                             const BlockDesc &bd, int lane)
+__device__ __forceinline__ void load_block_chars(const uint8_t *__restrict__ seq, const BlockDesc &bd, int lane, uint32_t (&raw)[4])
 {
     const uint64_t soff = bd.soff;
-    const uint32_t L = bd.len, j = bd.j;
+    if constexpr (AA) {
+        const uint32_t w0 = bd.j * kAaWinPerBlock;
+        const uint32_t nload = min(71u, bd.len - w0);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t q = (uint32_t)lane + 64u * k;
+            raw[k] = q < nload ? seq[soff + w0 + q] : 0u;
+        }
+        raw[2] = raw[3] = 0;
+    } else {
+        const uint32_t ts = bd.j * kDnaPosPerBlock;
+        const uint32_t nload = min(215u, bd.len - ts);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t q = (uint32_t)lane + 64u * k;
+            raw[k] = q < nload ? seq[soff + ts + q] : (uint32_t)'N';
+        }
+    }
+}
+
+// Leave the 4-residue half codes of one block in LDS (all lanes of the wave), from its raw characters.
+template <bool AA>
+__device__ __forceinline__ void encode_chars(typename WaveLds<AA>::type &l, const uint32_t (&raw)[4], int lane)
+{
     if constexpr (AA) {
         // ---- protein: windows i = 64j + lane
-        const uint32_t w0 = j * kAaWinPerBlock;
-        const uint32_t nload = min(71u, L - w0);
-        for (uint32_t q = lane; q < 72; q += 64) {
-            uint32_t c = q < nload ? seq[soff + w0 + q] : 0u;
-            l.code[q] = l.lut[c];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t q = (uint32_t)lane + 64u * k;
+            if (q < 72) l.code[q] = l.lut[raw[k] & 255u];
         }
         wave_sync();
         for (uint32_t q = lane; q < 68; q += 64) {
@@ -237,12 +260,11 @@ __device__ __forceinline__ void encode_block(typename WaveLds<AA>::type &l, cons
         }
         wave_sync();
     } else {
-        // ---- DNA: stage 215 bases, derive codon codes for both strands, then 4-codon half codes
-        const uint32_t ts = j * kDnaPosPerBlock;
-        const uint32_t nload = min(215u, L - ts);
-        for (uint32_t q = lane; q < 232; q += 64) {
-            uint32_t c = q < nload ? seq[soff + ts + q] : (uint32_t)'N';
-            l.bc[q] = (uint8_t)dna_code(c);
+        // ---- DNA: 215 bases -> base codes, codon codes for both strands, then 4-codon half codes
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t q = (uint32_t)lane + 64u * k;
+            if (q < 232) l.bc[q] = (uint8_t)dna_code(raw[k]);
         }
         wave_sync();
         for (uint32_t q = lane; q < 213; q += 64) {
@@ -267,6 +289,15 @@ __device__ __forceinline__ void encode_block(typename WaveLds<AA>::type &l, cons
         }
         wave_sync();
     }
+}
+
+template <bool AA>
+__device__ __forceinline__ void encode_block(typename WaveLds<AA>::type &l, const uint8_t *__restrict__ seq,
+                                             const BlockDesc &bd, int lane)
+{
+    uint32_t raw[4];
+    load_block_chars<AA>(seq, bd, lane, raw);
+    encode_chars<AA>(l, raw, lane);
 }
 
 // encodedKmer (KGJ:274-292) of the lane's window in row r (wave-uniform; DNA: strand r/3, phase r%3).
@@ -327,10 +358,10 @@ __device__ __forceinline__ void row_record_key(const BlockDesc &bd, int r, int l
 // k-mer, an empty slot or the end of the stream; never wrap).  16 tags per load, records touched only on a
 // fingerprint match; the rare longer walks share one copy of the generic walk, rows picked by register muxes.
 // On return bit q of the result is set iff query q was found, with ent[q] = the record's payload.
-template <int N, bool COUNTERS>
+template <int N, bool COUNTERS, bool HAVE_SLOT = false>
 __device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t (&val)[N], bool (&valid)[N],
                                             Payload (&ent)[N], unsigned long long &ctr_valid,
-                                            unsigned long long &ctr_slots)
+                                            unsigned long long &ctr_slots, const uint64_t *known_slot = nullptr)
 {
     uint64_t cand[N];     // slot under examination
     uint32_t fp[N], skip[N];
@@ -338,7 +369,7 @@ __device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t
     uint64_t home[COUNTERS ? N : 1];
 #pragma unroll
     for (int q = 0; q < N; q++) {
-        cand[q] = home_slot(val[q], tab);
+        cand[q] = HAVE_SLOT ? known_slot[q] : home_slot(val[q], tab);
         fp[q] = tag_of(val[q]);
         if (COUNTERS) { home[q] = cand[q]; if (valid[q]) ctr_valid++; }   // query k-mers (KGJ:913-920)
         valid[q] = valid[q] && cand[q] < tab.limit;     // beyond the stream: EOF, not found, nothing inspected

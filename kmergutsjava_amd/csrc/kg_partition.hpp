@@ -5,13 +5,12 @@
 // (profiles/r01_gather_ceiling*.jsonl), while L2-resident random reads run at 220-270 G/s.  So the query
 // k-mers are first bucketed by slot range (a bucket's tag range <= 2 MiB), then probed bucket by bucket with
 // all the workgroups of one XCD working on the same bucket.  The reference does the same thing for the same
-// reason with a sort and a sequential merge (KGJ:1076-1095, 944-1034); here it is one counting pass, one
-// scatter pass (8 bytes per query, written and read once, sequentially) and the probe pass.
+// reason with a sort and a sequential merge (KGJ:1076-1095, 944-1034); here it is one scatter pass (8 bytes
+// per query, written and read once in 128-byte lines) and the probe pass.
 //
-//   part_kernel<COUNT>   : encode every window; per-wave histogram over buckets                (no data moved)
-//   part_offsets_kernel  : exclusive scan per bucket over the waves + bucket starts
-//   part_kernel<SCATTER> : encode again; entry -> its wave's private region of its bucket (no global atomics,
-//                          deterministic layout, exact sizes)
+//   part_scatter_kernel  : encode every window once; entry -> 16-entry (128-byte) write-combining buffer of its
+//                          bucket in the workgroup's LDS -> the workgroup's over-allocated region of the bucket
+//                          (no counting pass, no per-entry global atomics; overflow list for skewed inputs)
 //   bucket_probe_kernel  : persistent workgroups; group x = blockIdx % 8 (XCD under round-robin placement,
 //                          speed only) walks the buckets b % 8 == x; 16-tag probe as in probe_n; a hit sets bit
 //                          `lane` in the 64-bit mask of its (block,row) and appends {id, payload} to an
@@ -42,229 +41,489 @@ __device__ __forceinline__ uint64_t home_slot_q(uint64_t v, uint64_t num_sigs, u
     return r;
 }
 
-constexpr uint64_t kEntInvalid = ~0ull;     // filler of the padded tail of a (wave, bucket) region
+constexpr uint64_t kEntInvalid = ~0ull;     // filler entry (padding of a 16-entry group)
+constexpr int kScatterWaves = 16;           // waves per scatter workgroup (one workgroup per CU: its LDS holds the buffers)
+constexpr uint32_t kGroup = 16;             // entries per write-combining buffer = one 128-byte line
+constexpr uint32_t kSpill = 768;            // entries that found their buffer full, per parity set (re-inserted after the flush)
 
 template <bool AA>
-inline size_t part_lds_bytes(bool scatter, uint32_t n_buckets)
+inline size_t scatter_lds_bytes(uint32_t n_buckets)
 {
     size_t enc = (sizeof(typename WaveLds<AA>::type) + 15) & ~(size_t)15;
-    return enc + (scatter ? (size_t)n_buckets * 32 + (size_t)n_buckets * 8 : (size_t)n_buckets * 4);
+    return enc * kScatterWaves + (size_t)n_buckets * (kGroup * 8 + 8) + (size_t)kSpill * 2 * 12 + 16;
 }
 
-// One wave per workgroup (the wave's LDS: encode scratch, per-bucket cursor, and in the scatter pass a
-// 4-entry = 32-byte write-combining buffer per bucket).  Regions of one (wave, bucket) pair are padded to a
-// multiple of 4 entries so that every flush is one aligned 32-byte sector; the padding carries kEntInvalid.
-// Two lanes of one step that target the same bucket are serialised by a claim word (last writer wins, the
-// others retry), so the buffers need no atomics.
-template <bool AA, bool SCATTER>
-__global__ __launch_bounds__(kWave) void part_kernel(
+// ---------------------------------------------------------------------------------------
+// Scatter pass: every window is encoded once; its entry goes into the workgroup's 16-entry buffer of its
+// bucket (LDS); a full buffer is written as one aligned 128-byte line into the workgroup's private region of
+// that bucket.  Regions are over-allocated (cap entries each, no counting pass); a group that does not fit its
+// region goes to the overflow list (skewed inputs), which is probed separately.  Layout of the entry array:
+// region (bucket b, workgroup w) = [ (b * n_wg + w) * cap , + fill[b * n_wg + w] ).
+template <bool AA>
+__global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t n_blocks, uint64_t limit,
-    uint64_t num_sigs, uint64_t magic, uint32_t shift, uint32_t n_buckets, uint32_t *__restrict__ M /* [bucket][wave] */,
-    const uint32_t *__restrict__ bstart, uint64_t *__restrict__ ent, unsigned long long *ctr)
+    uint64_t num_sigs, uint64_t magic, uint32_t shift, uint32_t n_buckets, uint32_t cap, uint64_t *__restrict__ ent,
+    uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap, uint32_t *__restrict__ ovf_bucket,
+    uint64_t *__restrict__ ovf_ent, unsigned long long *ctr)
 {
     constexpr int ROWS = AA ? 1 : 6;
-    // dynamic LDS (part_lds_bytes): encode scratch | [SCATTER: 4-entry buffers] | cursors | [SCATTER: claims]
-    extern __shared__ __attribute__((aligned(16))) unsigned char part_lds[];
     typedef typename WaveLds<AA>::type Enc;
-    Enc &l = *reinterpret_cast<Enc *>(part_lds);
     constexpr size_t enc_bytes = (sizeof(Enc) + 15) & ~(size_t)15;
-    uint64_t *buf = reinterpret_cast<uint64_t *>(part_lds + enc_bytes);
-    uint32_t *wpos = reinterpret_cast<uint32_t *>(part_lds + enc_bytes + (SCATTER ? (size_t)n_buckets * 32 : 0));
-    uint32_t *claim = wpos + n_buckets;                                     // COUNT: unused
-    const int lane = threadIdx.x;
-    const uint32_t wave_global = blockIdx.x;
-    const uint32_t n_waves = gridDim.x;
-    for (uint32_t b = lane; b < n_buckets; b += 64) {
-        wpos[b] = SCATTER ? M[(uint64_t)b * n_waves + wave_global] + bstart[b] : 0u;
-        if (SCATTER) { buf[4 * b] = kEntInvalid; buf[4 * b + 1] = kEntInvalid; buf[4 * b + 2] = kEntInvalid; buf[4 * b + 3] = kEntInvalid; }
-    }
-    encode_init<AA>(l, lane);          // ends with a wave_sync
+    extern __shared__ __attribute__((aligned(16))) unsigned char part_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Enc &l = *reinterpret_cast<Enc *>(part_lds + enc_bytes * wave);
+    uint64_t *buf = reinterpret_cast<uint64_t *>(part_lds + enc_bytes * kScatterWaves);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(buf + (size_t)n_buckets * kGroup);
+    uint32_t *wrel = cnt + n_buckets;                 // entries already written to this workgroup's region of bucket b
+    uint64_t *spill_e = reinterpret_cast<uint64_t *>(wrel + n_buckets + (n_buckets & 1u));     // [2][kSpill], 8-byte aligned
+    uint32_t *spill_b = reinterpret_cast<uint32_t *>(spill_e + 2 * kSpill);                     // [2][kSpill]
+    uint32_t *spill_n = spill_b + 2 * kSpill;                                                   // [2]
+    const uint32_t w = blockIdx.x, n_wg = gridDim.x;
+    for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) { cnt[b] = 0; wrel[b] = 0; }
+    if (threadIdx.x < 2) spill_n[threadIdx.x] = 0;
+    encode_init<AA>(l, lane);
+    __syncthreads();
+
+    // one 128-byte group out of LDS: into the region, or onto the overflow list when the region is full
+    auto flush_group = [&](uint32_t b) {
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(buf + (size_t)b * kGroup);
+        const uint32_t rel = wrel[b];
+        ulonglong2 *dst = nullptr;
+        if (rel + kGroup <= cap) {
+            dst = reinterpret_cast<ulonglong2 *>(ent + ((uint64_t)b * n_wg + w) * cap + rel);
+            wrel[b] = rel + kGroup;
+        } else {
+            const uint32_t g = atomicAdd(ovf_cursor, 1u);
+            if (g < ovf_cap) { ovf_bucket[g] = b; dst = reinterpret_cast<ulonglong2 *>(ovf_ent + (uint64_t)g * kGroup); }
+        }
+        if (dst) {
+#pragma unroll
+            for (int k = 0; k < (int)kGroup / 2; k++) dst[k] = src[k];
+        }
+    };
+
+    // an entry whose buffer is full: queue it (set `set`) for after the flush; if even the queue is full (heavy
+    // repeats) it goes to the overflow list as a group of its own
+    auto spill = [&](uint32_t set, uint32_t b, uint64_t e) {
+        const uint32_t sp = atomicAdd(&spill_n[set], 1u);
+        if (sp < kSpill) { spill_e[set * kSpill + sp] = e; spill_b[set * kSpill + sp] = b; }
+        else {
+            const uint32_t g = atomicAdd(ovf_cursor, 1u);
+            if (g < ovf_cap) {
+                ovf_bucket[g] = b;
+                uint64_t *dst = ovf_ent + (uint64_t)g * kGroup;
+                dst[0] = e;
+                for (uint32_t k = 1; k < kGroup; k++) dst[k] = kEntInvalid;
+            }
+        }
+    };
+    auto insert = [&](uint32_t set, uint32_t b, uint64_t e) {
+        const uint32_t at = atomicAdd(&cnt[b], 1u);
+        if (at < kGroup) buf[(size_t)b * kGroup + at] = e;
+        else spill(set, b, e);
+    };
 
     unsigned long long n_valid = 0;
-    for (uint32_t it = wave_global; it < n_blocks; it += n_waves) {
-        const BlockDesc bd = blocks[it];
-        encode_block<AA>(l, seq, bd, lane);
+    const uint32_t n_iter = (n_blocks + n_wg * kScatterWaves - 1) / (n_wg * kScatterWaves);
+    // the next block's descriptor and characters are fetched while the current block is encoded
+    BlockDesc bd_next;
+    uint32_t raw_next[4] = {0, 0, 0, 0};
+    {
+        const uint32_t it0 = w * kScatterWaves + (uint32_t)wave;
+        if (it0 < n_blocks) { bd_next = blocks[it0]; load_block_chars<AA>(seq, bd_next, lane, raw_next); }
+    }
+    for (uint32_t iter = 0; iter < n_iter; iter++) {
+        const uint32_t it = (iter * n_wg + w) * kScatterWaves + (uint32_t)wave;      // wave-uniform
+        uint64_t e[ROWS];
+        uint32_t bk[ROWS];
+        uint32_t pend = 0;
+        if (it < n_blocks) {
+            const BlockDesc bd = bd_next;
+            uint32_t raw[4] = {raw_next[0], raw_next[1], raw_next[2], raw_next[3]};
+            const uint32_t itn = it + n_wg * kScatterWaves;
+            if (itn < n_blocks) { bd_next = blocks[itn]; load_block_chars<AA>(seq, bd_next, lane, raw_next); }
+            encode_chars<AA>(l, raw, lane);
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            uint64_t v;
-            bool valid = row_value<AA>(l, r, lane, bd, &v);
-            uint32_t q;
-            const uint64_t slot = home_slot_q(v, num_sigs, magic, &q);
-            if (!SCATTER && valid) n_valid++;                       // query k-mers (KGJ:913-920)
-            valid = valid && slot < limit;                          // beyond the stream: never probed
-            const uint32_t b = (uint32_t)(slot >> shift);
-            if (!SCATTER) {
-                if (valid) atomicAdd(&wpos[b], 1u);
-            } else {
+            for (int r = 0; r < ROWS; r++) {
+                uint64_t v;
+                bool valid = row_value<AA>(l, r, lane, bd, &v);
+                uint32_t q;
+                const uint64_t slot = home_slot_q(v, num_sigs, magic, &q);
+                if (valid) n_valid++;                                   // query k-mers (KGJ:913-920)
+                valid = valid && slot < limit;                          // beyond the stream: never probed
+                bk[r] = (uint32_t)(slot >> shift);
                 const uint32_t low = (q << shift) | ((uint32_t)slot & ((1u << shift) - 1u));
                 const uint32_t id = (it << 9) | ((uint32_t)r << 6) | (uint32_t)lane;
-                const uint64_t e = ((uint64_t)id << 32) | low;
-                bool pending = valid;
-                while (__ballot(pending)) {
-                    if (pending) claim[b] = (uint32_t)lane;
-                    wave_sync();
-                    if (pending && claim[b] == (uint32_t)lane) {     // sole owner of bucket b in this round
-                        const uint32_t at = wpos[b];
-                        buf[4 * b + (at & 3u)] = e;
-                        wpos[b] = at + 1;
-                        if ((at & 3u) == 3u) {                       // sector complete: one aligned 32-byte write
-                            const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(&buf[4 * b]);
-                            const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(&buf[4 * b + 2]);
-                            ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(ent + (at - 3u));
-                            dst[0] = lo; dst[1] = hi;
-                            const ulonglong2 inv = make_ulonglong2(kEntInvalid, kEntInvalid);
-                            *reinterpret_cast<ulonglong2 *>(&buf[4 * b]) = inv;
-                            *reinterpret_cast<ulonglong2 *>(&buf[4 * b + 2]) = inv;
-                        }
-                        pending = false;
-                    }
-                    wave_sync();
-                }
+                e[r] = ((uint64_t)id << 32) | low;
+                if (valid) pend |= 1u << r;
             }
+            wave_sync();   // the wave's encode scratch is reused by its next block
         }
-        wave_sync();   // LDS is reused by the next block
-    }
-    if (!SCATTER) {
-        // padded to a multiple of 4 entries (see above)
-        for (uint32_t b = lane; b < n_buckets; b += 64) M[(uint64_t)b * n_waves + wave_global] = (wpos[b] + 3u) & ~3u;
-        for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
-        if (lane == 0) atomicAdd(&ctr[0], n_valid);
-    } else {
-        // partial last sectors, with their fillers
-        for (uint32_t b = lane; b < n_buckets; b += 64) {
-            const uint32_t at = wpos[b];
-            if (at & 3u) {
-                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(ent + (at & ~3u));
-                dst[0] = *reinterpret_cast<const ulonglong2 *>(&buf[4 * b]);
-                dst[1] = *reinterpret_cast<const ulonglong2 *>(&buf[4 * b + 2]);
-            }
+        // insert -> barrier -> flush the full buffers -> barrier -> re-insert what had found its buffer full.
+        // Two spill sets alternate so that the next iteration's inserts may overlap this iteration's re-inserts.
+        const uint32_t set = iter & 1u;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++)
+            if (pend & (1u << r)) insert(set, bk[r], e[r]);
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
+            if (cnt[b] >= kGroup) { flush_group(b); cnt[b] = 0; }
         }
+        if (threadIdx.x == 0) spill_n[set ^ 1u] = 0;
+        __syncthreads();
+        const uint32_t ns = min(spill_n[set], kSpill);
+        for (uint32_t i = threadIdx.x; i < ns; i += blockDim.x) insert(set ^ 1u, spill_b[set * kSpill + i], spill_e[set * kSpill + i]);
     }
-}
-
-// one workgroup per bucket: exclusive scan of the bucket's per-wave counts in place, total to tot[b]
-__global__ __launch_bounds__(256) void part_offsets_kernel(uint32_t *__restrict__ M, uint32_t n_waves, uint32_t *__restrict__ tot)
-{
-    __shared__ uint32_t lds[8];
-    __shared__ uint32_t carry;
-    uint32_t *row = M + (uint64_t)blockIdx.x * n_waves;
-    if (threadIdx.x == 0) carry = 0;
+    // drain what the last re-inserts queued
+    for (uint32_t set = n_iter & 1u;; set ^= 1u) {
+        __syncthreads();
+        const uint32_t ns = min(spill_n[set], kSpill);
+        if (ns == 0) break;                                   // uniform (read after the barrier)
+        for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
+            if (cnt[b] >= kGroup) { flush_group(b); cnt[b] = 0; }
+        }
+        if (threadIdx.x == 0) spill_n[set ^ 1u] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < ns; i += blockDim.x) insert(set ^ 1u, spill_b[set * kSpill + i], spill_e[set * kSpill + i]);
+        __syncthreads();
+        if (threadIdx.x == 0) spill_n[set] = 0;
+    }
     __syncthreads();
-    for (uint32_t base = 0; base < n_waves; base += 256 * 8) {
-        uint32_t v[8], s = 0;
-        const uint32_t i0 = base + threadIdx.x * 8;
-        for (int k = 0; k < 8; k++) { v[k] = i0 + k < n_waves ? row[i0 + k] : 0; s += v[k]; }
-        uint32_t total;
-        uint32_t run = carry + wg_exclusive_scan(s, &total, lds);
-        for (int k = 0; k < 8; k++) { if (i0 + k < n_waves) row[i0 + k] = run; run += v[k]; }
-        __syncthreads();
-        if (threadIdx.x == 0) carry += total;
-        __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
+        if (cnt[b] >= kGroup) { flush_group(b); cnt[b] = 0; }      // full buffers left by the last re-inserts
     }
-    if (threadIdx.x == 0) tot[blockIdx.x] = carry;
+    __syncthreads();
+    // partial groups, padded with fillers
+    for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
+        const uint32_t c = cnt[b];
+        if (c) {
+            for (uint32_t k = c; k < kGroup; k++) buf[(size_t)b * kGroup + k] = kEntInvalid;
+            flush_group(b);
+        }
+        fill[(uint64_t)b * n_wg + w] = wrel[b];
+    }
+    for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
+    if (lane == 0 && n_valid) atomicAdd(&ctr[0], n_valid);
 }
 
-// single workgroup: bstart[b] = sum of tot[0..b), bstart[n] = total
-__global__ __launch_bounds__(256) void part_bstart_kernel(const uint32_t *__restrict__ tot, uint32_t n_buckets,
-                                                          uint32_t *__restrict__ bstart, uint64_t *total_out)
+// ---------------------------------------------------------------------------------------
+// State of a wave's reservation in the unordered hit list.
+struct UListState { unsigned long long base; uint32_t used; bool have; };
+
+// Probe N entries of bucket b per lane and emit the hits: set the lane's bit in the 64-bit mask of its
+// (block,row) and append {id, payload} to the unordered list (wave-private chunk reservations).
+template <bool AA, int N, bool COUNTERS>
+__device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, uint32_t shift, const uint64_t (&e)[N],
+                                              kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used,
+                                              unsigned long long *cursor, uint64_t ulist_cap,
+                                              unsigned long long *__restrict__ masks, UListState &u,
+                                              unsigned long long &ctr_slots, int lane)
 {
-    __shared__ uint32_t lds[8];
-    uint32_t v[4], s = 0;
-    const uint32_t i0 = threadIdx.x * 4;
-    for (int k = 0; k < 4; k++) { v[k] = i0 + k < n_buckets ? tot[i0 + k] : 0; s += v[k]; }
-    uint32_t total;
-    uint32_t run = wg_exclusive_scan(s, &total, lds);
-    for (int k = 0; k < 4; k++) { if (i0 + k <= n_buckets) bstart[i0 + k] = run; run += v[k]; }
-    if (threadIdx.x == 0) *total_out = total;
+    constexpr uint32_t ROWS = AA ? 1 : 6;
+    uint64_t val[N], slot[N];
+    bool valid[N];
+    uint32_t id[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        valid[k] = e[k] != kEntInvalid;
+        const uint32_t low = (uint32_t)e[k];
+        id[k] = (uint32_t)(e[k] >> 32);
+        slot[k] = ((uint64_t)b << shift) | (low & ((1u << shift) - 1u));
+        val[k] = (uint64_t)(low >> shift) * tab.num_sigs + slot[k];
+    }
+    Payload pay[N];
+    unsigned long long ctr_dummy = 0;
+    const uint32_t foundm = probe_n<N, COUNTERS, true>(tab, val, valid, pay, ctr_dummy, ctr_slots, slot);
+    uint32_t cnt[N], rank[N], total = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const bool f = (foundm >> k) & 1u;
+        const unsigned long long m = __ballot(f);
+        cnt[k] = (uint32_t)__popcll(m);
+        rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        total += cnt[k];
+        if (f) atomicOr(&masks[(uint64_t)(id[k] >> 9) * ROWS + ((id[k] >> 6) & 7u)], 1ull << (id[k] & 63u));
+    }
+    if (total) {
+        if (u.used + total > kUChunk) {                      // uniform: retire the chunk, take a new one
+            if (lane == 0 && u.have && u.base + kUChunk <= ulist_cap) chunk_used[u.base / kUChunk] = u.used;
+            unsigned long long nb = 0;
+            if (lane == 0) nb = atomicAdd(cursor, (unsigned long long)kUChunk);
+            nb = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(nb >> 32)) << 32) |
+                 (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)nb);
+            u.base = nb; u.used = 0; u.have = true;
+        }
+        if (u.base + kUChunk <= ulist_cap) {
+            uint32_t at = u.used;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                if ((foundm >> k) & 1u) {
+                    kg_hit h;
+                    h.container = id[k];
+                    h.from0InProt = 0;
+                    h.oI = pay[k].oI; h.avgOffFromEnd = pay[k].avg; h.fI = pay[k].fI; h.functionWt = pay[k].wt;
+                    ulist[u.base + at + rank[k]] = h;
+                }
+                at += cnt[k];
+            }
+        }
+        u.used += total;
+    }
 }
 
-// Work distribution: the workgroups with blockIdx % 8 == x (one XCD under round-robin placement -- measured,
-// tools/xcd_affinity.hip; speed only, never correctness) walk the buckets b % 8 == x in order and take chunks
-// of the current bucket from a per-bucket counter, so an XCD's L2 holds one bucket's tags (two at a hand-over).
-template <bool AA, bool COUNTERS>
-__global__ __launch_bounds__(256) void bucket_probe_kernel(
-    const uint8_t *__restrict__ entries, const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, uint64_t magic,
-    const uint64_t *__restrict__ ent, const uint32_t *__restrict__ bstart, uint32_t n_buckets, uint32_t shift,
-    uint32_t *next_chunk /* [n_buckets], zeroed */, kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used,
-    unsigned long long *cursor, uint64_t ulist_cap, unsigned long long *__restrict__ masks, unsigned long long *ctr)
+// ---------------------------------------------------------------------------------------
+// The bucket pass is split in two so that its inner loop only ever waits for the L2:
+//   tag pass    : per entry, walk the tags (L2-resident) to the first empty slot or fingerprint match; a match
+//                 becomes a 16-byte candidate record {value, id, slots walked}.  Never touches the 24-byte records.
+//   verify pass : one lane per candidate: fetch the record (random line from HBM, thousands in flight), compare the
+//                 key, emit the hit; a fingerprint collision keeps walking (generic, rare).
+struct CandRec { uint64_t val; uint32_t id; uint32_t walked; };
+static_assert(sizeof(CandRec) == 16, "CandRec must be 16 bytes");
+
+// reserve `total` (<= kUChunk) consecutive records of a chunked list for this wave; ~0 when the list is full
+__device__ __forceinline__ unsigned long long chunk_reserve(UListState &u, uint32_t total, uint32_t *__restrict__ chunk_used,
+                                                            unsigned long long *cursor, uint64_t cap, int lane)
+{
+    if (u.used + total > kUChunk) {                          // uniform: retire the chunk, take a new one
+        if (lane == 0 && u.have && u.base + kUChunk <= cap) chunk_used[u.base / kUChunk] = u.used;
+        unsigned long long nb = 0;
+        if (lane == 0) nb = atomicAdd(cursor, (unsigned long long)kUChunk);
+        nb = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(nb >> 32)) << 32) |
+             (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)nb);
+        u.base = nb; u.used = 0; u.have = true;
+    }
+    const unsigned long long at = u.base + u.used;
+    u.used += total;
+    return u.base + kUChunk <= cap ? at : ~0ull;
+}
+
+__device__ __forceinline__ void chunk_finish(const UListState &u, uint32_t *__restrict__ chunk_used, uint64_t cap, int lane)
+{
+    if (lane == 0 && u.have && u.base + kUChunk <= cap) chunk_used[u.base / kUChunk] = u.used;
+}
+
+// Tag pass work distribution: the workgroups with blockIdx % 8 == x (one XCD under round-robin placement --
+// measured, tools/xcd_affinity.hip; speed only, never correctness) walk the buckets b % 8 == x in order and take
+// the bucket's regions one at a time from a per-bucket counter, so an XCD's L2 holds one bucket's tags (two at a
+// hand-over).
+template <bool COUNTERS>
+__global__ __launch_bounds__(256) void bucket_tag_kernel(
+    const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, const uint64_t *__restrict__ ent,
+    const uint32_t *__restrict__ fill, uint32_t n_regions, uint32_t cap, uint32_t n_buckets, uint32_t shift,
+    uint32_t *next_region /* [n_buckets], zeroed */, CandRec *__restrict__ cand, uint32_t *__restrict__ cand_used,
+    unsigned long long *cand_cursor, uint64_t cand_cap, unsigned long long *ctr)
 {
     constexpr int N = kProbeN;
-    constexpr uint32_t ROWS = AA ? 1 : 6;
-    constexpr uint32_t kChunk = 256u * N * 2u;         // entries per grab
-    __shared__ uint32_t s_chunk;
+    __shared__ uint32_t s_region;
     const int lane = threadIdx.x & 63;
-    TableView tab;
-    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic;
-    unsigned long long ctr_dummy = 0, ctr_slots = 0;
-    unsigned long long cur_base = 0;                   // this wave's reservation in the unordered list (uniform)
-    uint32_t cur_used = kUChunk;                       // "full": the first append takes a chunk
-    bool have_chunk = false;
+    unsigned long long ctr_slots = 0;
+    UListState u;
+    u.base = 0; u.used = kUChunk; u.have = false;      // "full": the first append takes a chunk
 
+    // a grab = kGrab consecutive entry slots of one region (regions are cap slots long; slots past the region's
+    // fill are empty grabs): fine enough that every workgroup of the XCD stays busy until the bucket is done
+    constexpr uint32_t kGrab = 256u * N * 2u;
+    const uint32_t grabs_per_region = (cap + kGrab - 1) / kGrab;
+    const uint32_t n_grabs = n_regions * grabs_per_region;
     for (uint32_t b = blockIdx.x & 7u; b < n_buckets; b += 8) {
-        const uint32_t lo = bstart[b], hi = bstart[b + 1];
         for (;;) {
             __syncthreads();
-            if (threadIdx.x == 0) s_chunk = atomicAdd(&next_chunk[b], 1u);
+            if (threadIdx.x == 0) s_region = atomicAdd(&next_region[b], 1u);
             __syncthreads();
-            const uint64_t c_lo = (uint64_t)lo + (uint64_t)s_chunk * kChunk;
-            if (c_lo >= hi) break;                      // bucket exhausted (uniform): next bucket of this group
-            for (uint32_t c0 = (uint32_t)c_lo; c0 < hi && c0 < c_lo + kChunk; c0 += 256u * N) {
-                uint64_t val[N];
+            const uint32_t g = s_region;
+            if (g >= n_grabs) break;                    // bucket exhausted (uniform): next bucket of this group
+            const uint32_t w = g / grabs_per_region, g0 = (g % grabs_per_region) * kGrab;
+            const uint32_t n = fill[(uint64_t)b * n_regions + w];
+            const uint64_t *src = ent + ((uint64_t)b * n_regions + w) * cap;
+            for (uint32_t c0 = g0; c0 < n && c0 < g0 + kGrab; c0 += 256u * N) {
+                uint64_t val[N], home[N], cur[N];
+                uint32_t id[N], fp[N], skip[N];
                 bool valid[N];
-                uint32_t id[N];
+                Tags16 tg[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) {
                     const uint32_t i = c0 + (uint32_t)k * 256u + threadIdx.x;
-                    const uint64_t e = i < hi ? ent[i] : kEntInvalid;
+                    const uint64_t e = i < n ? src[i] : kEntInvalid;
                     valid[k] = e != kEntInvalid;
                     const uint32_t low = (uint32_t)e;
                     id[k] = (uint32_t)(e >> 32);
-                    const uint64_t slot = ((uint64_t)b << shift) | (low & ((1u << shift) - 1u));
-                    val[k] = (uint64_t)(low >> shift) * num_sigs + slot;
+                    home[k] = ((uint64_t)b << shift) | (low & ((1u << shift) - 1u));
+                    val[k] = (uint64_t)(low >> shift) * num_sigs + home[k];
+                    fp[k] = tag_of(val[k]);
+                    cur[k] = probe_window(home[k], &skip[k]);
+                    if (valid[k]) tg[k] = load_tags(tags + cur[k]);
                 }
-                Payload pay[N];
-                const uint32_t foundm = probe_n<N, COUNTERS>(tab, val, valid, pay, ctr_dummy, ctr_slots);
-
-                // hits: set the lane's bit in the (block,row) mask; append {id, payload} to the unordered list
+                uint32_t candm = 0, pend = 0;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    if (valid[k]) {
+                        bool emp;
+                        const int i = first_stop(tg[k], fp[k], &emp, skip[k]);
+                        if (i == 16) { pend |= 1u << k; cur[k] += 16; }
+                        else {
+                            cur[k] += (uint64_t)i;
+                            if (!emp) candm |= 1u << k;
+                            else if (COUNTERS) ctr_slots += (cur[k] < limit ? cur[k] + 1 : limit) - home[k];
+                        }
+                    }
+                }
+                while (__ballot(pend != 0)) {            // walks longer than 16 slots (rare), tags only
+                    if (pend) {
+                        const int r = __builtin_ctz(pend);
+                        uint64_t sl = cur[0], hm = home[0];
+                        uint32_t f = fp[0];
+#pragma unroll
+                        for (int k = 1; k < N; k++)
+                            if (r == k) { sl = cur[k]; f = fp[k]; hm = home[k]; }
+                        bool done = false, is_cand = false;
+                        if (sl >= limit) { done = true; sl = limit; }
+                        else {
+                            const Tags16 x = load_tags(tags + sl);
+                            bool emp;
+                            const int i = first_stop(x, f, &emp);
+                            if (i == 16) sl += 16;
+                            else { sl += (uint64_t)i; done = true; is_cand = !emp; }
+                        }
+#pragma unroll
+                        for (int k = 0; k < N; k++)
+                            if (r == k) { cur[k] = sl; if (is_cand) candm |= 1u << k; }
+                        if (done) {
+                            pend &= pend - 1;
+                            if (COUNTERS && !is_cand) ctr_slots += (sl < limit ? sl + 1 : limit) - hm;
+                        }
+                    }
+                }
+                // candidates -> list
                 uint32_t cnt[N], rank[N], total = 0;
 #pragma unroll
                 for (int k = 0; k < N; k++) {
-                    const bool f = (foundm >> k) & 1u;
-                    const unsigned long long m = __ballot(f);
+                    const unsigned long long m = __ballot((candm >> k) & 1u);
                     cnt[k] = (uint32_t)__popcll(m);
                     rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     total += cnt[k];
-                    if (f) atomicOr(&masks[(uint64_t)(id[k] >> 9) * ROWS + ((id[k] >> 6) & 7u)], 1ull << (id[k] & 63u));
                 }
                 if (total) {
-                    if (cur_used + total > kUChunk) {               // uniform: retire the chunk, take a new one
-                        if (lane == 0 && have_chunk && cur_base + kUChunk <= ulist_cap) chunk_used[cur_base / kUChunk] = cur_used;
-                        unsigned long long nb = 0;
-                        if (lane == 0) nb = atomicAdd(cursor, (unsigned long long)kUChunk);
-                        nb = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(nb >> 32)) << 32) |
-                             (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)nb);
-                        cur_base = nb; cur_used = 0; have_chunk = true;
-                    }
-                    if (cur_base + kUChunk <= ulist_cap) {
-                        uint32_t at = cur_used;
+                    unsigned long long at = chunk_reserve(u, total, cand_used, cand_cursor, cand_cap, lane);
+                    if (at != ~0ull) {
 #pragma unroll
                         for (int k = 0; k < N; k++) {
-                            if ((foundm >> k) & 1u) {
-                                kg_hit h;
-                                h.container = id[k];
-                                h.from0InProt = 0;
-                                h.oI = pay[k].oI; h.avgOffFromEnd = pay[k].avg; h.fI = pay[k].fI; h.functionWt = pay[k].wt;
-                                ulist[cur_base + at + rank[k]] = h;
+                            if ((candm >> k) & 1u) {
+                                CandRec c;
+                                c.val = val[k]; c.id = id[k]; c.walked = (uint32_t)(cur[k] - home[k]);
+                                cand[at + rank[k]] = c;
                             }
                             at += cnt[k];
                         }
                     }
-                    cur_used += total;
                 }
             }
         }
     }
-    if (lane == 0 && have_chunk && cur_base + kUChunk <= ulist_cap) chunk_used[cur_base / kUChunk] = cur_used;
+    chunk_finish(u, cand_used, cand_cap, lane);
+    if (COUNTERS) {
+        for (int off = 32; off > 0; off >>= 1) ctr_slots += __shfl_down(ctr_slots, off);
+        if (lane == 0) atomicAdd(&ctr[1], ctr_slots);
+    }
+}
+
+// Verify pass: one wave per candidate chunk at a time, one lane per candidate.
+template <bool AA, bool COUNTERS>
+__global__ __launch_bounds__(256) void verify_kernel(
+    const uint8_t *__restrict__ entries, const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, uint64_t magic,
+    const CandRec *__restrict__ cand, const uint32_t *__restrict__ cand_used, const unsigned long long *cand_cursor,
+    uint64_t cand_cap, kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used, unsigned long long *cursor,
+    uint64_t ulist_cap, unsigned long long *__restrict__ masks, unsigned long long *ctr)
+{
+    constexpr uint32_t ROWS = AA ? 1 : 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * 4;
+    TableView tab;
+    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic;
+    const unsigned long long cur = *cand_cursor;
+    const uint32_t n_chunks = (uint32_t)((cur < cand_cap ? cur : cand_cap) / kUChunk);
+    unsigned long long ctr_slots = 0;
+    UListState u;
+    u.base = 0; u.used = kUChunk; u.have = false;
+    for (uint32_t c = wave_global; c < n_chunks; c += n_waves) {
+        const uint32_t used = cand_used[c];
+        for (uint32_t k0 = 0; k0 < used; k0 += 64) {
+            const bool act = k0 + (uint32_t)lane < used;
+            CandRec r;
+            r.val = 0; r.id = 0; r.walked = 0;
+            if (act) r = cand[(uint64_t)c * kUChunk + k0 + lane];
+            const uint64_t home = home_slot(r.val, tab);
+            uint64_t s = home + r.walked;
+            bool found = false;
+            Entry e;
+            e.key = 0; e.oI = e.avg = e.fI = 0; e.wt = 0.f;
+            if (act) {
+                e = load_entry(tab, s);
+                found = e.key == (int64_t)r.val;
+                if (!found) {                              // fingerprint collision: keep walking (KGJ:944-1034 semantics)
+                    const uint32_t f = tag_of(r.val);
+                    s += 1;
+                    for (;;) {
+                        if (s >= limit) { s = limit; break; }
+                        const Tags16 x = load_tags(tab.tags + s);
+                        bool emp;
+                        const int i = first_stop(x, f, &emp);
+                        if (i == 16) { s += 16; continue; }
+                        s += (uint64_t)i;
+                        if (emp) break;
+                        e = load_entry(tab, s);
+                        if (e.key == (int64_t)r.val) { found = true; break; }
+                        s += 1;
+                    }
+                }
+                if (COUNTERS) ctr_slots += (s < limit ? s + 1 : limit) - home;
+            }
+            const unsigned long long m = __ballot(found);
+            const uint32_t total = (uint32_t)__popcll(m);
+            if (found) atomicOr(&masks[(uint64_t)(r.id >> 9) * ROWS + ((r.id >> 6) & 7u)], 1ull << (r.id & 63u));
+            if (total) {
+                const unsigned long long at = chunk_reserve(u, total, chunk_used, cursor, ulist_cap, lane);
+                if (at != ~0ull && found) {
+                    kg_hit h;
+                    h.container = r.id;
+                    h.from0InProt = 0;
+                    h.oI = e.oI; h.avgOffFromEnd = e.avg; h.fI = e.fI; h.functionWt = e.wt;
+                    ulist[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = h;
+                }
+            }
+        }
+    }
+    chunk_finish(u, chunk_used, ulist_cap, lane);
+    if (COUNTERS) {
+        for (int off = 32; off > 0; off >>= 1) ctr_slots += __shfl_down(ctr_slots, off);
+        if (lane == 0) atomicAdd(&ctr[1], ctr_slots);
+    }
+}
+
+// Overflow groups (regions that filled up: heavily repeated k-mers): one wave per 16-entry group.
+template <bool AA, bool COUNTERS>
+__global__ __launch_bounds__(256) void overflow_probe_kernel(
+    const uint8_t *__restrict__ entries, const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, uint64_t magic,
+    const uint32_t *__restrict__ ovf_bucket, const uint64_t *__restrict__ ovf_ent, const uint32_t *__restrict__ ovf_cursor,
+    uint32_t ovf_cap, uint32_t shift, kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used, unsigned long long *cursor, uint64_t ulist_cap,
+    unsigned long long *__restrict__ masks, unsigned long long *ctr)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * 4;
+    TableView tab;
+    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic;
+    unsigned long long ctr_slots = 0;
+    UListState u;
+    u.base = 0; u.used = kUChunk; u.have = false;
+    const uint32_t n_groups = min(*ovf_cursor, ovf_cap);
+    for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
+        const uint32_t b = ovf_bucket[g];
+        uint64_t e[1];
+        e[0] = lane < (int)kGroup ? ovf_ent[(uint64_t)g * kGroup + lane] : kEntInvalid;
+        probe_entries<AA, 1, COUNTERS>(tab, b, shift, e, ulist, chunk_used, cursor, ulist_cap, masks, u, ctr_slots, lane);
+    }
+    if (lane == 0 && u.have && u.base + kUChunk <= ulist_cap) chunk_used[u.base / kUChunk] = u.used;
     if (COUNTERS) {
         for (int off = 32; off > 0; off >>= 1) ctr_slots += __shfl_down(ctr_slots, off);
         if (lane == 0) atomicAdd(&ctr[1], ctr_slots);

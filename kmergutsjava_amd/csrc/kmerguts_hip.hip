@@ -9,7 +9,9 @@
 #include "kg_aggregate.hpp"
 #include "kg_partition.hpp"
 
+#include <algorithm>
 #include <cerrno>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -467,6 +469,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         // bucket = 2^shift slots (= bytes of tags); at most kMaxBuckets buckets; quotient must fit 32 - shift bits
         uint32_t shift = env_u32("KG_PART_SHIFT", 21u);
         while (((t->limit + (1ull << shift) - 1) >> shift) > (uint64_t)kg::kMaxBuckets) shift++;
+        // the scatter workgroup keeps a 128-byte buffer per bucket in LDS: at most 160 KiB with its encode scratch
+        while (AA ? kg::scatter_lds_bytes<true>((uint32_t)((t->limit + (1ull << shift) - 1) >> shift)) > 160u * 1024
+                  : kg::scatter_lds_bytes<false>((uint32_t)((t->limit + (1ull << shift) - 1) >> shift)) > 160u * 1024)
+            shift++;
         const uint64_t qmax = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1;
         const bool fits = shift < 32 && qmax < (1ull << (32 - shift)) && nblocks <= (1ull << 23);
         // Measured at 1 Gbp x 33.6 GB table (profiles/r01_partition_path.md): direct 31 ms; partitioned 57 ms
@@ -477,90 +483,129 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         part_shift = shift;
         part_buckets = (uint32_t)((t->limit + (1ull << shift) - 1) >> shift);
     }
+    bool part_done = false;
     if (use_part) {
-        const uint32_t part_grid = env_u32("KG_PART_GRID", 256u * 5u);       // single-wave workgroups, ~5 per CU (LDS)
-        const uint32_t n_waves = part_grid;
-        uint32_t *d_M = nullptr, *d_tot = nullptr, *d_bstart = nullptr;
-        if ((rc = sc.get(&d_M, (size_t)part_buckets * n_waves))) return rc;
-        if ((rc = sc.get(&d_tot, (size_t)part_buckets + 8))) return rc;
-        if ((rc = sc.get(&d_bstart, (size_t)part_buckets + 8))) return rc;
+        constexpr uint32_t WIN = AA ? 64u : 384u;                                    // windows per block
+        const uint32_t per_iter = kg::kScatterWaves;
+        uint32_t n_wg = env_u32("KG_PART_WGS", 256u);
+        if ((uint64_t)n_wg * per_iter > nblocks) n_wg = (uint32_t)((nblocks + per_iter - 1) / per_iter);
+        const uint64_t blocks_per_wg = ((nblocks + (uint64_t)n_wg * per_iter - 1) / ((uint64_t)n_wg * per_iter)) * per_iter;
+        // region capacity: the mean if every window were valid and hashed uniformly, plus 6 sigma, in 16-entry groups
+        const double mean = (double)blocks_per_wg * WIN / (double)part_buckets * (env_u32("KG_PART_SLACK", 100u) / 100.0);
+        const uint32_t cap = (uint32_t)(((uint64_t)(mean + 6.0 * std::sqrt(mean) + 32.0) + 15) / 16 * 16);
+        const uint64_t n_regions_total = (uint64_t)part_buckets * n_wg;
+        const uint32_t ovf_cap = env_u32("KG_PART_OVF_GROUPS", (uint32_t)std::min<uint64_t>(1u << 22, std::max<uint64_t>(4096, n_regions_total * cap / 16 / 64)));
+        uint64_t *d_ent = nullptr, *d_ovf_ent = nullptr;
+        uint32_t *d_fill = nullptr, *d_ovf_bucket = nullptr, *d_next = nullptr, *d_ovfc = nullptr;
+        unsigned long long *d_masks = nullptr;
+        if ((rc = sc.get(&d_ent, (size_t)(n_regions_total * cap)))) return rc;
+        if ((rc = sc.get(&d_fill, (size_t)n_regions_total))) return rc;
+        if ((rc = sc.get(&d_ovf_ent, (size_t)ovf_cap * kg::kGroup))) return rc;
+        if ((rc = sc.get(&d_ovf_bucket, (size_t)ovf_cap))) return rc;
+        if ((rc = sc.get(&d_next, (size_t)part_buckets + 8))) return rc;
+        if ((rc = sc.get(&d_ovfc, 8))) return rc;
+        if ((rc = sc.get(&d_masks, (size_t)n_rows))) return rc;
         unsigned long long *d_cursor = (unsigned long long *)(d_totals + 1);
         unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
         HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
-        HIP_TRY(hipEventRecord(t->ev[1], t->stream));
-        const dim3 pg(part_grid), pb(kg::kWave);
-        hipLaunchKernelGGL((kg::part_kernel<AA, false>), pg, pb, kg::part_lds_bytes<AA>(false, part_buckets), t->stream, d_seq, d_blocks, (uint32_t)nblocks, t->limit,
-                           (uint64_t)t->num_sigs, t->magic, part_shift, part_buckets, d_M, (const uint32_t *)nullptr,
-                           (uint64_t *)nullptr, d_ctr);
-        hipLaunchKernelGGL(kg::part_offsets_kernel, dim3(part_buckets), dim3(256), 0, t->stream, d_M, n_waves, d_tot);
-        hipLaunchKernelGGL(kg::part_bstart_kernel, dim3(1), dim3(256), 0, t->stream, d_tot, part_buckets, d_bstart, d_totals + 5);
-        HIP_TRY(hipGetLastError());
-        uint64_t h_ent = 0;
-        HIP_TRY(hipMemcpyAsync(&h_ent, d_totals + 5, 8, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        uint64_t *d_ent = nullptr;
-        if ((rc = sc.get(&d_ent, (size_t)h_ent + 4))) return rc;
-        hipLaunchKernelGGL((kg::part_kernel<AA, true>), pg, pb, kg::part_lds_bytes<AA>(true, part_buckets), t->stream, d_seq, d_blocks, (uint32_t)nblocks, t->limit,
-                           (uint64_t)t->num_sigs, t->magic, part_shift, part_buckets, d_M, d_bstart, d_ent, d_ctr);
-        HIP_TRY(hipGetLastError());
-        unsigned long long *d_masks = nullptr;
-        uint32_t *d_next = nullptr;
-        if ((rc = sc.get(&d_masks, (size_t)n_rows))) return rc;
-        if ((rc = sc.get(&d_next, (size_t)part_buckets + 8))) return rc;
+        HIP_TRY(hipMemsetAsync(d_ovfc, 0, 32, t->stream));
         HIP_TRY(hipMemsetAsync(d_masks, 0, n_rows * 8, t->stream));
+        const size_t lds = kg::scatter_lds_bytes<AA>(part_buckets);
+        HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipEventRecord(t->ev[1], t->stream));
+        hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
+                           d_blocks, (uint32_t)nblocks, t->limit, (uint64_t)t->num_sigs, t->magic, part_shift, part_buckets, cap,
+                           d_ent, d_fill, d_ovfc, ovf_cap, d_ovf_bucket, d_ovf_ent, d_ctr);
+        HIP_TRY(hipGetLastError());
         const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 4u) & ~7u;
-        uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio) + (uint64_t)probe_grid * 4 * kg::kUChunk + 4096 +
+        uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio) + (uint64_t)(probe_grid + 64) * 4 * kg::kUChunk + 4096 +
                          kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         kg_hit *d_ulist = nullptr;
-        uint32_t *d_cused = nullptr;
+        uint32_t *d_cused = nullptr, *d_candused = nullptr;
+        kg::CandRec *d_cand = nullptr;
         uint64_t n_chunks = 0;
-        for (int attempt = 0; attempt < 2; attempt++) {
+        bool too_skewed = false;
+        // candidates = fingerprint matches (hits + ~0.4 % of the probes): a little above the hit list
+        uint64_t ccap = ((uint64_t)((double)windows * (t->stage_ratio * 1.25 + 0.01)) + (uint64_t)probe_grid * 4 * kg::kUChunk +
+                         4096 + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
+        unsigned long long *d_ccursor = (unsigned long long *)(d_totals + 6);
+        const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
+        for (int attempt = 0; attempt < 3; attempt++) {
             if ((rc = dalloc(t, (void **)&d_ulist, ucap * sizeof(kg_hit)))) return rc;
             if ((rc = dalloc(t, (void **)&d_cused, (ucap / kg::kUChunk + 1) * 4))) { sc.adopt(d_ulist); return rc; }
+            if ((rc = dalloc(t, (void **)&d_cand, ccap * sizeof(kg::CandRec)))) { sc.adopt(d_ulist); sc.adopt(d_cused); return rc; }
+            if ((rc = dalloc(t, (void **)&d_candused, (ccap / kg::kUChunk + 1) * 4))) { sc.adopt(d_ulist); sc.adopt(d_cused); sc.adopt(d_cand); return rc; }
             HIP_TRY(hipMemsetAsync(d_cused, 0, (ucap / kg::kUChunk + 1) * 4, t->stream));
+            HIP_TRY(hipMemsetAsync(d_candused, 0, (ccap / kg::kUChunk + 1) * 4, t->stream));
             HIP_TRY(hipMemsetAsync(d_cursor, 0, 8, t->stream));
+            HIP_TRY(hipMemsetAsync(d_ccursor, 0, 8, t->stream));
             HIP_TRY(hipMemsetAsync(d_totals + 3, 0, 8, t->stream));      // slots_inspected of a re-run starts over
             HIP_TRY(hipMemsetAsync(d_next, 0, ((size_t)part_buckets + 8) * 4, t->stream));
-            if (counters)
-                hipLaunchKernelGGL((kg::bucket_probe_kernel<AA, true>), dim3(probe_grid), dim3(256), 0, t->stream, t->d_entries,
-                                   t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic, d_ent, d_bstart, part_buckets, part_shift,
-                                   d_next, d_ulist, d_cused, d_cursor, ucap, d_masks, d_ctr);
-            else
-                hipLaunchKernelGGL((kg::bucket_probe_kernel<AA, false>), dim3(probe_grid), dim3(256), 0, t->stream, t->d_entries,
-                                   t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic, d_ent, d_bstart, part_buckets, part_shift,
-                                   d_next, d_ulist, d_cused, d_cursor, ucap, d_masks, d_ctr);
+#define KG_PROBE_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic
+#define KG_ULIST_ARGS d_ulist, d_cused, d_cursor, ucap, d_masks, d_ctr
+#define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, d_ent, d_fill, n_wg, cap, part_buckets, part_shift, d_next, d_cand, \
+                    d_candused, d_ccursor, ccap, d_ctr
+            if (counters) {
+                hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, t->stream, KG_TAG_ARGS);
+                hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, t->stream, KG_PROBE_ARGS, d_cand,
+                                   d_candused, d_ccursor, ccap, KG_ULIST_ARGS);
+                hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(64), dim3(256), 0, t->stream, KG_PROBE_ARGS,
+                                   d_ovf_bucket, d_ovf_ent, d_ovfc, ovf_cap, part_shift, KG_ULIST_ARGS);
+            } else {
+                hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, t->stream, KG_TAG_ARGS);
+                hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, t->stream, KG_PROBE_ARGS, d_cand,
+                                   d_candused, d_ccursor, ccap, KG_ULIST_ARGS);
+                hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(64), dim3(256), 0, t->stream, KG_PROBE_ARGS,
+                                   d_ovf_bucket, d_ovf_ent, d_ovfc, ovf_cap, part_shift, KG_ULIST_ARGS);
+            }
+#undef KG_TAG_ARGS
+#undef KG_PROBE_ARGS
+#undef KG_ULIST_ARGS
             HIP_TRY(hipGetLastError());
             st.scan_launches++;
-            uint64_t h_cur = 0;
+            uint64_t h_cur = 0, h_ccur = 0;
+            uint32_t h_ovf = 0;
             HIP_TRY(hipMemcpyAsync(&h_cur, d_cursor, 8, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(&h_ccur, d_ccursor, 8, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(&h_ovf, d_ovfc, 4, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
+            if (h_ovf > ovf_cap) { too_skewed = true; break; }           // more overflow than provisioned: direct path
             n_chunks = h_cur / kg::kUChunk;
-            if (h_cur <= ucap) break;
-            dfree(t, d_ulist); dfree(t, d_cused); d_ulist = nullptr; d_cused = nullptr;       // stream is idle here
-            if (attempt == 1) return fail(KG_ERR_DEVICE, "hit list overflow after resize (internal error)");
-            ucap = h_cur;                 // masks are idempotent (atomicOr): the re-run sets the same bits
+            if (h_cur <= ucap && h_ccur <= ccap) break;
+            // a list was too small: now the exact need is known (masks are idempotent: the re-run sets the same bits)
+            dfree(t, d_ulist); dfree(t, d_cused); dfree(t, d_cand); dfree(t, d_candused);     // stream is idle here
+            d_ulist = nullptr; d_cused = nullptr; d_cand = nullptr; d_candused = nullptr;
+            if (attempt == 2) return fail(KG_ERR_DEVICE, "hit list overflow after resize (internal error)");
+            if (h_ccur > ccap) { ccap = h_ccur; ucap = std::max<uint64_t>(ucap, h_ccur); }     // hits <= candidates
+            else ucap = h_cur;
         }
+        sc.adopt(d_cand); sc.adopt(d_candused);
         sc.adopt(d_ulist); sc.adopt(d_cused);
-        HIP_TRY(hipEventRecord(t->ev[2], t->stream));
-        hipLaunchKernelGGL((kg::rows_from_masks_kernel<AA>), dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, t->stream,
-                           d_blocks, (uint32_t)nblocks, d_masks, d_counts);
-        if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) return rc;
-        uint64_t h_tot[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 32, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        n_hits = h_tot[0];
-        st.windows_valid = counters ? (int64_t)h_tot[2] : -1;
-        st.slots_inspected = counters ? (int64_t)h_tot[3] : -1;
-        if (windows) {
-            double ratio = (double)n_hits / (double)windows * 1.1 + 1e-3;
-            if (ratio > t->stage_ratio) t->stage_ratio = ratio > 1.0 ? 1.0 : ratio;
+        if (!too_skewed) {
+            HIP_TRY(hipEventRecord(t->ev[2], t->stream));
+            hipLaunchKernelGGL((kg::rows_from_masks_kernel<AA>), dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, t->stream,
+                               d_blocks, (uint32_t)nblocks, d_masks, d_counts);
+            if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) return rc;
+            uint64_t h_tot[4] = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 32, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            n_hits = h_tot[0];
+            st.windows_valid = counters ? (int64_t)h_tot[2] : -1;
+            st.slots_inspected = counters ? (int64_t)h_tot[3] : -1;
+            if (windows) {
+                double ratio = (double)n_hits / (double)windows * 1.1 + 1e-3;
+                if (ratio > t->stage_ratio) t->stage_ratio = ratio > 1.0 ? 1.0 : ratio;
+            }
+            st.n_hits = (int64_t)n_hits;
+            if ((rc = dalloc(t, (void **)&res->d_hits, n_hits * sizeof(kg_hit)))) return rc;
+            if (n_chunks)
+                hipLaunchKernelGGL((kg::place_unordered_kernel<AA>), dim3((uint32_t)n_chunks), dim3(256), 0, t->stream, d_blocks,
+                                   d_masks, d_offs, d_ulist, d_cused, (uint32_t)n_chunks, res->d_hits);
+            part_done = true;
         }
-        st.n_hits = (int64_t)n_hits;
-        if ((rc = dalloc(t, (void **)&res->d_hits, n_hits * sizeof(kg_hit)))) return rc;
-        if (n_chunks)
-            hipLaunchKernelGGL((kg::place_unordered_kernel<AA>), dim3((uint32_t)n_chunks), dim3(256), 0, t->stream, d_blocks,
-                               d_masks, d_offs, d_ulist, d_cused, (uint32_t)n_chunks, res->d_hits);
-    } else {
+    }
+    if (!part_done) {
+        st.scan_launches = 0;
     // ---- scan: encode + probe + staged compaction; re-run once if the staging area was too small ----
     // persistent grid: enough workgroups to fill 256 CUs, few enough that per-wave staging chunks stay small
     const uint32_t scan_grid = env_u32("KG_SCAN_GRID", 256u * 8u);

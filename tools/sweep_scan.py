@@ -16,10 +16,11 @@ lens = synth.contig_mix_lengths(total_bp, 301); off = synth.offsets_of(lens)
 seq = synth.random_dna(int(off[-1]), 302, dev)
 torch.cuda.synchronize()
 variants = [dict(KG_PARTITION=0)]
-for shift in (20, 21, 22):
-    variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=shift, KG_PART_GRID=1024, KG_PROBE_GRID=1024))
-for pg, qg in ((512, 1024), (1536, 1024), (1024, 512), (1024, 2048)):
-    variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=21, KG_PART_GRID=pg, KG_PROBE_GRID=qg))
+for qg in (1024, 1792, 2048, 3584):
+    variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=21, KG_PROBE_GRID=qg, KG_VERIFY_GRID=2048))
+for shift in (20, 22):
+    variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=shift, KG_PROBE_GRID=1792, KG_VERIFY_GRID=2048))
+variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=21, KG_PROBE_GRID=1792, KG_VERIFY_GRID=4096))
 ref = None
 for v in variants:
     for k, x in v.items():
