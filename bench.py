@@ -43,10 +43,13 @@ def main():
     ap.add_argument("--load", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bp", type=int, default=10_000_000)
+    ap.add_argument("--strategy", choices=["auto", "direct", "partitioned"], default="auto",
+                    help="scan strategy of the library (KG_PARTITION): auto picks partitioned probing for large inputs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
                                                       "rehearsing the multi-rank path on a one-GPU box)")
     args = ap.parse_args()
 
+    os.environ["KG_PARTITION"] = {"auto": "2", "direct": "0", "partitioned": "1"}[args.strategy]
     import torch.distributed as dist
     from kmergutsjava_amd import hotpath, synth
     from kmergutsjava_amd import distributed as kd
@@ -114,9 +117,14 @@ def main():
     barrier()
     t1 = time.perf_counter()
     scan_ms, total_ms, agg_ms, order_ms = [], [], [], []
+    pass_ms = {"part_scatter_kernel": [], "bucket_tag_kernel": [], "verify_kernel": []}
     hits = calls = 0
+    partitioned = False
     for _ in range(args.steps):
         st = step()
+        partitioned = bool(st["partitioned"])
+        pass_ms["part_scatter_kernel"].append(st["ms_part_scatter"]); pass_ms["bucket_tag_kernel"].append(st["ms_part_tag"])
+        pass_ms["verify_kernel"].append(st["ms_part_verify"])
         scan_ms.append(st["ms_scan"]); total_ms.append(st["ms_total"])
         agg_ms.append(st["ms_aggregate"]); order_ms.append(st["ms_order"])
         hits, calls = st["n_hits"], st["n_calls"]
@@ -140,7 +148,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("total_bp") == args.total_bp and tj.get("num_sigs") == args.num_sigs:
+                if (tj.get("total_bp") == args.total_bp and tj.get("num_sigs") == args.num_sigs and
+                        tj.get("strategy") == ("partitioned" if partitioned else "direct")):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -162,7 +171,11 @@ def main():
                        "parallelism": "contig shards x%d, table replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "kg::scan_kernel<false,false,3>", "kernel_ms": ms_scan,
+                         "kernel": ("scan stage = kg::part_scatter_kernel + kg::bucket_tag_kernel + kg::verify_kernel"
+                                    if partitioned else "kg::scan_kernel<false,false,3>"),
+                         "kernel_ms": ms_scan,
+                         "passes_ms": ({k: float(np.mean(v)) for k, v in pass_ms.items()} if partitioned else None),
+                         "strategy": "partitioned" if partitioned else "direct",
                          "alg_bytes_per_residue": b_alg, "slots_per_residue": p_bar, "hits_per_residue": h_bar,
                          "residues_per_launch": int(residues)},
             "stage_ms": {"scan": ms_scan, "order": float(np.mean(order_ms)), "aggregate": float(np.mean(agg_ms)),

@@ -92,7 +92,12 @@ typedef struct kg_stats {
     float   ms_aggregate;        /* gatherHits / processSetOfHits kernels                                */
     float   ms_total;            /* first kernel start -> last kernel end on the library's stream        */
     int32_t scan_launches;       /* >1 when the hit staging buffer had to grow and the scan was re-run   */
-    int32_t reserved;
+    int32_t partitioned;         /* 1: the scan stage ran as scatter + tag + verify passes (kg_partition.hpp), */
+                                 /* 0: as the single direct-probing kernel                                    */
+    float   ms_part_scatter;     /* partitioned only: the three passes that make up ms_scan                    */
+    float   ms_part_tag;
+    float   ms_part_verify;
+    float   reserved;
 } kg_stats;
 
 typedef struct kg_table  kg_table;

@@ -45,7 +45,8 @@ class KgStats(C.Structure):
                 ("windows", C.c_int64), ("windows_valid", C.c_int64), ("slots_inspected", C.c_int64),
                 ("table_bytes", C.c_int64), ("ms_scan", C.c_float), ("ms_order", C.c_float),
                 ("ms_aggregate", C.c_float), ("ms_total", C.c_float), ("scan_launches", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("partitioned", C.c_int32), ("ms_part_scatter", C.c_float), ("ms_part_tag", C.c_float),
+                ("ms_part_verify", C.c_float), ("reserved", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

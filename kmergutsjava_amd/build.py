@@ -32,8 +32,9 @@ def _stale(target: str, sources) -> bool:
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
-    srcs = [os.path.join(CSRC, "kmerguts_hip.hip"), os.path.join(CSRC, "kg_device.hpp"),
-            os.path.join(ROOT, "include", "kmerguts_hip.h")]
+    # the translation unit first, then everything it includes (a header edit must trigger a rebuild)
+    srcs = [os.path.join(CSRC, "kmerguts_hip.hip")] + sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(ROOT, "include", "kmerguts_hip.h")]
     if force or _stale(LIB, srcs):
         cmd = [_hipcc(), *HIPCC_FLAGS, "-o", LIB, srcs[0]]
         if verbose:

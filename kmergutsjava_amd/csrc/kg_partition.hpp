@@ -44,13 +44,12 @@ __device__ __forceinline__ uint64_t home_slot_q(uint64_t v, uint64_t num_sigs, u
 constexpr uint64_t kEntInvalid = ~0ull;     // filler entry (padding of a 16-entry group)
 constexpr int kScatterWaves = 16;           // waves per scatter workgroup (one workgroup per CU: its LDS holds the buffers)
 constexpr uint32_t kGroup = 16;             // entries per write-combining buffer = one 128-byte line
-constexpr uint32_t kSpill = 768;            // entries that found their buffer full, per parity set (re-inserted after the flush)
 
 template <bool AA>
 inline size_t scatter_lds_bytes(uint32_t n_buckets)
 {
     size_t enc = (sizeof(typename WaveLds<AA>::type) + 15) & ~(size_t)15;
-    return enc * kScatterWaves + (size_t)n_buckets * (kGroup * 8 + 8) + (size_t)kSpill * 2 * 12 + 16;
+    return enc * kScatterWaves + (size_t)n_buckets * (kGroup * 8 + 8);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -75,12 +74,8 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     uint64_t *buf = reinterpret_cast<uint64_t *>(part_lds + enc_bytes * kScatterWaves);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(buf + (size_t)n_buckets * kGroup);
     uint32_t *wrel = cnt + n_buckets;                 // entries already written to this workgroup's region of bucket b
-    uint64_t *spill_e = reinterpret_cast<uint64_t *>(wrel + n_buckets + (n_buckets & 1u));     // [2][kSpill], 8-byte aligned
-    uint32_t *spill_b = reinterpret_cast<uint32_t *>(spill_e + 2 * kSpill);                     // [2][kSpill]
-    uint32_t *spill_n = spill_b + 2 * kSpill;                                                   // [2]
     const uint32_t w = blockIdx.x, n_wg = gridDim.x;
     for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) { cnt[b] = 0; wrel[b] = 0; }
-    if (threadIdx.x < 2) spill_n[threadIdx.x] = 0;
     encode_init<AA>(l, lane);
     __syncthreads();
 
@@ -100,27 +95,6 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
 #pragma unroll
             for (int k = 0; k < (int)kGroup / 2; k++) dst[k] = src[k];
         }
-    };
-
-    // an entry whose buffer is full: queue it (set `set`) for after the flush; if even the queue is full (heavy
-    // repeats) it goes to the overflow list as a group of its own
-    auto spill = [&](uint32_t set, uint32_t b, uint64_t e) {
-        const uint32_t sp = atomicAdd(&spill_n[set], 1u);
-        if (sp < kSpill) { spill_e[set * kSpill + sp] = e; spill_b[set * kSpill + sp] = b; }
-        else {
-            const uint32_t g = atomicAdd(ovf_cursor, 1u);
-            if (g < ovf_cap) {
-                ovf_bucket[g] = b;
-                uint64_t *dst = ovf_ent + (uint64_t)g * kGroup;
-                dst[0] = e;
-                for (uint32_t k = 1; k < kGroup; k++) dst[k] = kEntInvalid;
-            }
-        }
-    };
-    auto insert = [&](uint32_t set, uint32_t b, uint64_t e) {
-        const uint32_t at = atomicAdd(&cnt[b], 1u);
-        if (at < kGroup) buf[(size_t)b * kGroup + at] = e;
-        else spill(set, b, e);
     };
 
     unsigned long long n_valid = 0;
@@ -159,40 +133,24 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
             }
             wave_sync();   // the wave's encode scratch is reused by its next block
         }
-        // insert -> barrier -> flush the full buffers -> barrier -> re-insert what had found its buffer full.
-        // Two spill sets alternate so that the next iteration's inserts may overlap this iteration's re-inserts.
-        const uint32_t set = iter & 1u;
+        // insert; entries that find their buffer full wait for the flush and try again.  (A spill queue that
+        // re-inserts after the flush was tried: same time, and with 16 waves a quarter of the entries spill.)
+        int more;
+        do {
 #pragma unroll
-        for (int r = 0; r < ROWS; r++)
-            if (pend & (1u << r)) insert(set, bk[r], e[r]);
-        __syncthreads();
-        for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
-            if (cnt[b] >= kGroup) { flush_group(b); cnt[b] = 0; }
-        }
-        if (threadIdx.x == 0) spill_n[set ^ 1u] = 0;
-        __syncthreads();
-        const uint32_t ns = min(spill_n[set], kSpill);
-        for (uint32_t i = threadIdx.x; i < ns; i += blockDim.x) insert(set ^ 1u, spill_b[set * kSpill + i], spill_e[set * kSpill + i]);
+            for (int r = 0; r < ROWS; r++) {
+                if (pend & (1u << r)) {
+                    const uint32_t at = atomicAdd(&cnt[bk[r]], 1u);
+                    if (at < kGroup) { buf[(size_t)bk[r] * kGroup + at] = e[r]; pend &= ~(1u << r); }
+                }
+            }
+            __syncthreads();
+            for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
+                if (cnt[b] >= kGroup) { flush_group(b); cnt[b] = 0; }
+            }
+            more = __syncthreads_or(pend != 0);
+        } while (more);
     }
-    // drain what the last re-inserts queued
-    for (uint32_t set = n_iter & 1u;; set ^= 1u) {
-        __syncthreads();
-        const uint32_t ns = min(spill_n[set], kSpill);
-        if (ns == 0) break;                                   // uniform (read after the barrier)
-        for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
-            if (cnt[b] >= kGroup) { flush_group(b); cnt[b] = 0; }
-        }
-        if (threadIdx.x == 0) spill_n[set ^ 1u] = 0;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < ns; i += blockDim.x) insert(set ^ 1u, spill_b[set * kSpill + i], spill_e[set * kSpill + i]);
-        __syncthreads();
-        if (threadIdx.x == 0) spill_n[set] = 0;
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
-        if (cnt[b] >= kGroup) { flush_group(b); cnt[b] = 0; }      // full buffers left by the last re-inserts
-    }
-    __syncthreads();
     // partial groups, padded with fillers
     for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
         const uint32_t c = cnt[b];
@@ -310,8 +268,9 @@ template <bool COUNTERS>
 __global__ __launch_bounds__(256) void bucket_tag_kernel(
     const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, const uint64_t *__restrict__ ent,
     const uint32_t *__restrict__ fill, uint32_t n_regions, uint32_t cap, uint32_t n_buckets, uint32_t shift,
-    uint32_t *next_region /* [n_buckets], zeroed */, CandRec *__restrict__ cand, uint32_t *__restrict__ cand_used,
-    unsigned long long *cand_cursor, uint64_t cand_cap, unsigned long long *ctr)
+    uint32_t grab /* entry slots per hand-out, multiple of 256 * kProbeN */, uint32_t *next_region /* [n_buckets], zeroed */,
+    CandRec *__restrict__ cand, uint32_t *__restrict__ cand_used, unsigned long long *cand_cursor, uint64_t cand_cap,
+    unsigned long long *ctr)
 {
     constexpr int N = kProbeN;
     __shared__ uint32_t s_region;
@@ -320,9 +279,9 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
     UListState u;
     u.base = 0; u.used = kUChunk; u.have = false;      // "full": the first append takes a chunk
 
-    // a grab = kGrab consecutive entry slots of one region (regions are cap slots long; slots past the region's
-    // fill are empty grabs): fine enough that every workgroup of the XCD stays busy until the bucket is done
-    constexpr uint32_t kGrab = 256u * N * 2u;
+    // a grab = `grab` consecutive entry slots of one region (regions are cap slots long; slots past the region's
+    // fill are empty grabs).  Measured: whole regions (256 per bucket) 10.8 ms, 2048-slot grabs 11.6 ms.
+    const uint32_t kGrab = grab;
     const uint32_t grabs_per_region = (cap + kGrab - 1) / kGrab;
     const uint32_t n_grabs = n_regions * grabs_per_region;
     for (uint32_t b = blockIdx.x & 7u; b < n_buckets; b += 8) {
@@ -543,11 +502,38 @@ __global__ void rows_from_masks_kernel(const BlockDesc *__restrict__ blocks, uin
     counts[row_index<AA>(bd, it, (int)r)] = (uint32_t)__popcll(masks[t]);
 }
 
+// One 24-byte record per (block,row): everything the placement of a hit needs, so that it costs one random line
+// per hit instead of three (block descriptor, mask, offset).
+struct RowInfo {
+    unsigned long long mask;     // hit lanes of the row
+    uint32_t off;                // index of the row's first hit in hits[]
+    uint32_t container;
+    int32_t pos0;                // from0InProt of lane 0's window
+    int32_t step;                // +1: positions ascend with the lane ('+' rows, proteins); -1: they descend ('-' rows)
+};
+static_assert(sizeof(RowInfo) == 24, "RowInfo must be 24 bytes");
+
+template <bool AA>
+__global__ void row_info_kernel(const BlockDesc *__restrict__ blocks, uint32_t n_blocks,
+                                const unsigned long long *__restrict__ masks, const uint32_t *__restrict__ offs,
+                                RowInfo *__restrict__ info)
+{
+    constexpr uint32_t ROWS = AA ? 1 : 6;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n_blocks * ROWS) return;
+    const uint32_t it = (uint32_t)(t / ROWS), r = (uint32_t)(t % ROWS);
+    const BlockDesc bd = blocks[it];
+    RowInfo ri;
+    ri.mask = masks[t];
+    ri.off = offs[row_index<AA>(bd, it, (int)r)];
+    row_record_key<AA>(bd, (int)r, 0, &ri.container, &ri.pos0);
+    ri.step = (!AA && r >= 3) ? -1 : 1;
+    info[t] = ri;
+}
+
 // unordered list -> hits[] ordered by (container, from0InProt); one workgroup per reservation chunk
 template <bool AA>
-__global__ __launch_bounds__(256) void place_unordered_kernel(const BlockDesc *__restrict__ blocks,
-                                                              const unsigned long long *__restrict__ masks,
-                                                              const uint32_t *__restrict__ offs,
+__global__ __launch_bounds__(256) void place_unordered_kernel(const RowInfo *__restrict__ info,
                                                               const kg_hit *__restrict__ ulist,
                                                               const uint32_t *__restrict__ chunk_used, uint32_t n_chunks,
                                                               kg_hit *__restrict__ hits)
@@ -560,12 +546,12 @@ __global__ __launch_bounds__(256) void place_unordered_kernel(const BlockDesc *_
         kg_hit h = ulist[(uint64_t)c * kUChunk + k];
         const uint32_t id = h.container;
         const uint32_t it = id >> 9, r = (id >> 6) & 7u, ln = id & 63u;
-        const BlockDesc bd = blocks[it];
-        const unsigned long long m = masks[(uint64_t)it * ROWS + r];
+        const RowInfo ri = info[(uint64_t)it * ROWS + r];
         // '+' rows ascend with the lane, '-' rows descend (see scan_kernel)
-        const unsigned long long before = (!AA && r >= 3) ? (ln == 63 ? 0ull : (m >> (ln + 1))) : (m & ((1ull << ln) - 1ull));
-        row_record_key<AA>(bd, (int)r, (int)ln, &h.container, &h.from0InProt);
-        hits[(uint64_t)offs[row_index<AA>(bd, it, (int)r)] + (uint32_t)__popcll(before)] = h;
+        const unsigned long long before = ri.step < 0 ? (ln == 63 ? 0ull : (ri.mask >> (ln + 1))) : (ri.mask & ((1ull << ln) - 1ull));
+        h.container = ri.container;
+        h.from0InProt = ri.pos0 + ri.step * (int32_t)ln;
+        hits[(uint64_t)ri.off + (uint32_t)__popcll(before)] = h;
     }
 }
 

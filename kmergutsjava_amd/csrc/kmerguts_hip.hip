@@ -107,7 +107,7 @@ struct kg_table {
     uint64_t magic = 0;
     uint64_t occupied = 0;
     double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};
     DevCache cache;
 };
 
@@ -475,11 +475,12 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
             shift++;
         const uint64_t qmax = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1;
         const bool fits = shift < 32 && qmax < (1ull << (32 - shift)) && nblocks <= (1ull << 23);
-        // Measured at 1 Gbp x 33.6 GB table (profiles/r01_partition_path.md): direct 31 ms; partitioned 57 ms
-        // (count 15.6 + scatter 26.9 + probe 14.7): the L2-resident probe is 2x faster, but encoding twice and
-        // the scatter pass cost more than it saves.  So: opt-in only (KG_PARTITION=1), parity-tested either way.
-        const uint32_t mode = env_u32("KG_PARTITION", 0u);       // 0 direct probing (default), 1 partitioned whenever possible
-        use_part = fits && nblocks > 0 && mode == 1;
+        // Measured at 1 Gbp x 33.6 GB table (profiles/r01_partition_path.md): direct 31.9 ms; partitioned 27.1 ms
+        // (scatter 13.9 + tag 10.8 + verify 2.5) with 5x less DRAM traffic.  Small inputs and L2/MALL-sized tables
+        // stay on the direct kernel.  KG_PARTITION: 0 direct, 1 partitioned whenever possible, 2 (default) auto.
+        const uint32_t mode = env_u32("KG_PARTITION", 2u);
+        const bool worth = t->limit >= (64ull << 20) && windows >= (1ull << 27);
+        use_part = fits && nblocks > 0 && (mode == 1 || (mode == 2 && worth));
         part_shift = shift;
         part_buckets = (uint32_t)((t->limit + (1ull << shift) - 1) >> shift);
     }
@@ -530,6 +531,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                          4096 + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         unsigned long long *d_ccursor = (unsigned long long *)(d_totals + 6);
         const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
+        const uint32_t grab_unit = 256u * kg::kProbeN;
+        const uint32_t probe_grab = (std::max(env_u32("KG_PROBE_GRAB", cap), grab_unit) + grab_unit - 1) / grab_unit * grab_unit;
         for (int attempt = 0; attempt < 3; attempt++) {
             if ((rc = dalloc(t, (void **)&d_ulist, ucap * sizeof(kg_hit)))) return rc;
             if ((rc = dalloc(t, (void **)&d_cused, (ucap / kg::kUChunk + 1) * 4))) { sc.adopt(d_ulist); return rc; }
@@ -543,16 +546,19 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
             HIP_TRY(hipMemsetAsync(d_next, 0, ((size_t)part_buckets + 8) * 4, t->stream));
 #define KG_PROBE_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic
 #define KG_ULIST_ARGS d_ulist, d_cused, d_cursor, ucap, d_masks, d_ctr
-#define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, d_ent, d_fill, n_wg, cap, part_buckets, part_shift, d_next, d_cand, \
+#define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, d_ent, d_fill, n_wg, cap, part_buckets, part_shift, probe_grab, d_next, d_cand, \
                     d_candused, d_ccursor, ccap, d_ctr
+            HIP_TRY(hipEventRecord(t->ev[5], t->stream));
             if (counters) {
                 hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, t->stream, KG_TAG_ARGS);
+                HIP_TRY(hipEventRecord(t->ev[6], t->stream));
                 hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, t->stream, KG_PROBE_ARGS, d_cand,
                                    d_candused, d_ccursor, ccap, KG_ULIST_ARGS);
                 hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(64), dim3(256), 0, t->stream, KG_PROBE_ARGS,
                                    d_ovf_bucket, d_ovf_ent, d_ovfc, ovf_cap, part_shift, KG_ULIST_ARGS);
             } else {
                 hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, t->stream, KG_TAG_ARGS);
+                HIP_TRY(hipEventRecord(t->ev[6], t->stream));
                 hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, t->stream, KG_PROBE_ARGS, d_cand,
                                    d_candused, d_ccursor, ccap, KG_ULIST_ARGS);
                 hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(64), dim3(256), 0, t->stream, KG_PROBE_ARGS,
@@ -562,6 +568,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
 #undef KG_PROBE_ARGS
 #undef KG_ULIST_ARGS
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(t->ev[7], t->stream));
             st.scan_launches++;
             uint64_t h_cur = 0, h_ccur = 0;
             uint32_t h_ovf = 0;
@@ -569,6 +576,19 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
             HIP_TRY(hipMemcpyAsync(&h_ccur, d_ccursor, 8, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipMemcpyAsync(&h_ovf, d_ovfc, 4, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
+            if (getenv("KG_DEBUG")) {
+                std::vector<uint32_t> hf((size_t)n_regions_total);
+                (void)hipMemcpy(hf.data(), d_fill, hf.size() * 4, hipMemcpyDeviceToHost);
+                uint64_t sum = 0; uint32_t mx = 0, mn = ~0u; uint64_t full = 0;
+                for (uint32_t v : hf) { sum += v; mx = std::max(mx, v); mn = std::min(mn, v); full += v + 16 > cap; }
+                fprintf(stderr, "[kg] region fill: sum %llu, min %u, max %u, full regions %llu\n", (unsigned long long)sum, mn, mx,
+                        (unsigned long long)full);
+            }
+            if (getenv("KG_DEBUG"))
+                fprintf(stderr, "[kg] partition attempt %d: overflow groups %u (cap %u), hit list %llu (cap %llu), candidates %llu (cap %llu), "
+                                "regions %llu x %u entries, %u buckets, shift %u, %u scatter workgroups\n",
+                        attempt, h_ovf, ovf_cap, (unsigned long long)h_cur, (unsigned long long)ucap, (unsigned long long)h_ccur,
+                        (unsigned long long)ccap, (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg);
             if (h_ovf > ovf_cap) { too_skewed = true; break; }           // more overflow than provisioned: direct path
             n_chunks = h_cur / kg::kUChunk;
             if (h_cur <= ucap && h_ccur <= ccap) break;
@@ -598,10 +618,16 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
             }
             st.n_hits = (int64_t)n_hits;
             if ((rc = dalloc(t, (void **)&res->d_hits, n_hits * sizeof(kg_hit)))) return rc;
-            if (n_chunks)
-                hipLaunchKernelGGL((kg::place_unordered_kernel<AA>), dim3((uint32_t)n_chunks), dim3(256), 0, t->stream, d_blocks,
-                                   d_masks, d_offs, d_ulist, d_cused, (uint32_t)n_chunks, res->d_hits);
+            if (n_chunks) {
+                kg::RowInfo *d_info = nullptr;
+                if ((rc = sc.get(&d_info, (size_t)n_rows))) return rc;
+                hipLaunchKernelGGL((kg::row_info_kernel<AA>), dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, t->stream,
+                                   d_blocks, (uint32_t)nblocks, d_masks, d_offs, d_info);
+                hipLaunchKernelGGL((kg::place_unordered_kernel<AA>), dim3((uint32_t)n_chunks), dim3(256), 0, t->stream, d_info,
+                                   d_ulist, d_cused, (uint32_t)n_chunks, res->d_hits);
+            }
             part_done = true;
+            st.partitioned = 1;
         }
     }
     if (!part_done) {
@@ -727,6 +753,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
     HIP_TRY(hipEventElapsedTime(&ms, t->ev[2], t->ev[3])); st.ms_order = ms;
     HIP_TRY(hipEventElapsedTime(&ms, t->ev[3], t->ev[4])); st.ms_aggregate = ms;
     HIP_TRY(hipEventElapsedTime(&ms, t->ev[0], t->ev[4])); st.ms_total = ms;
+    if (st.partitioned) {
+        HIP_TRY(hipEventElapsedTime(&ms, t->ev[1], t->ev[5])); st.ms_part_scatter = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, t->ev[5], t->ev[6])); st.ms_part_tag = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, t->ev[6], t->ev[7])); st.ms_part_verify = ms;
+    }
     return KG_OK;
 }
 

@@ -17,6 +17,25 @@ def assert_same_records(gpu, ora, what=""):
     go, oo = gpu.otu(), ora["otu"]
     assert go.tobytes() == oo.tobytes(), "%s OTU records differ (first diff at %s)" % (what, _first_diff(go, oo))
     assert gpu.stats["residues"] == ora["residues"], what + " residues"
+    import os
+    mode = os.environ.get("KG_PARTITION")
+    if mode == "0":
+        assert gpu.stats["partitioned"] == 0, what + ": direct strategy requested"
+    if mode == "1" and gpu.stats["n_blocks"] > 0 and os.environ.get("KG_PART_OVF_GROUPS") is None and _partition_fits(gpu.stats):
+        assert gpu.stats["partitioned"] == 1, what + ": the partitioned strategy fell back to direct probing"
+
+
+def _partition_fits(stats) -> bool:
+    """The library's own eligibility rule for the partitioned strategy (kmerguts_hip.hip, scan_impl)."""
+    num_sigs = stats["table_bytes"] // 24
+    shift = 21
+    while ((num_sigs + (1 << shift) - 1) >> shift) > 1024:
+        shift += 1
+    enc = 2416 * 16 if stats["n_containers"] != stats["n_seqs"] else 656 * 16
+    while enc + ((num_sigs + (1 << shift) - 1) >> shift) * 136 > 160 * 1024:
+        shift += 1
+    qmax = 20 ** 8 // num_sigs + 1
+    return shift < 32 and qmax < (1 << (32 - shift)) and stats["n_blocks"] <= (1 << 23)
 
 
 def _first_diff(a, b):
