@@ -117,14 +117,13 @@ def main():
     barrier()
     t1 = time.perf_counter()
     scan_ms, total_ms, agg_ms, order_ms = [], [], [], []
-    pass_ms = {"part_scatter_kernel": [], "bucket_tag_kernel": [], "verify_kernel": []}
+    pass_ms = {"scatter_until_last_chunk": [], "tag_verify_tail": []}
     hits = calls = 0
     partitioned = False
     for _ in range(args.steps):
         st = step()
         partitioned = bool(st["partitioned"])
-        pass_ms["part_scatter_kernel"].append(st["ms_part_scatter"]); pass_ms["bucket_tag_kernel"].append(st["ms_part_tag"])
-        pass_ms["verify_kernel"].append(st["ms_part_verify"])
+        pass_ms["scatter_until_last_chunk"].append(st["ms_part_scatter"]); pass_ms["tag_verify_tail"].append(st["ms_part_verify"])
         scan_ms.append(st["ms_scan"]); total_ms.append(st["ms_total"])
         agg_ms.append(st["ms_aggregate"]); order_ms.append(st["ms_order"])
         hits, calls = st["n_hits"], st["n_calls"]
@@ -171,8 +170,8 @@ def main():
                        "parallelism": "contig shards x%d, table replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("scan stage = kg::part_scatter_kernel + kg::bucket_tag_kernel + kg::verify_kernel"
-                                    if partitioned else "kg::scan_kernel<false,false,3>"),
+                         "kernel": ("scan stage = kg::part_scatter_kernel || kg::bucket_tag_kernel (4 chunks, two streams) + "
+                                    "kg::verify_kernel" if partitioned else "kg::scan_kernel<false,false,3>"),
                          "kernel_ms": ms_scan,
                          "passes_ms": ({k: float(np.mean(v)) for k, v in pass_ms.items()} if partitioned else None),
                          "strategy": "partitioned" if partitioned else "direct",

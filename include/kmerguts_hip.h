@@ -94,9 +94,9 @@ typedef struct kg_stats {
     int32_t scan_launches;       /* >1 when the hit staging buffer had to grow and the scan was re-run   */
     int32_t partitioned;         /* 1: the scan stage ran as scatter + tag + verify passes (kg_partition.hpp), */
                                  /* 0: as the single direct-probing kernel                                    */
-    float   ms_part_scatter;     /* partitioned only: the three passes that make up ms_scan                    */
-    float   ms_part_tag;
-    float   ms_part_verify;
+    float   ms_part_scatter;     /* partitioned only: start of ms_scan until the last chunk is scattered        */
+    float   ms_part_tag;         /* (unused: the tag passes overlap the scatter passes of later chunks)         */
+    float   ms_part_verify;      /* partitioned only: what remains of the tag / verify passes after that        */
     float   reserved;
 } kg_stats;
 

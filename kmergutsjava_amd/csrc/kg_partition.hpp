@@ -60,8 +60,8 @@ inline size_t scatter_lds_bytes(uint32_t n_buckets)
 // region (bucket b, workgroup w) = [ (b * n_wg + w) * cap , + fill[b * n_wg + w] ).
 template <bool AA>
 __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
-    const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t n_blocks, uint64_t limit,
-    uint64_t num_sigs, uint64_t magic, uint32_t shift, uint32_t n_buckets, uint32_t cap, uint64_t *__restrict__ ent,
+    const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t block_lo, uint32_t n_blocks /* of this launch */,
+    uint64_t limit, uint64_t num_sigs, uint64_t magic, uint32_t shift, uint32_t n_buckets, uint32_t cap, uint64_t *__restrict__ ent,
     uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap, uint32_t *__restrict__ ovf_bucket,
     uint64_t *__restrict__ ovf_ent, unsigned long long *ctr)
 {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     uint32_t raw_next[4] = {0, 0, 0, 0};
     {
         const uint32_t it0 = w * kScatterWaves + (uint32_t)wave;
-        if (it0 < n_blocks) { bd_next = blocks[it0]; load_block_chars<AA>(seq, bd_next, lane, raw_next); }
+        if (it0 < n_blocks) { bd_next = blocks[block_lo + it0]; load_block_chars<AA>(seq, bd_next, lane, raw_next); }
     }
     for (uint32_t iter = 0; iter < n_iter; iter++) {
         const uint32_t it = (iter * n_wg + w) * kScatterWaves + (uint32_t)wave;      // wave-uniform
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
             const BlockDesc bd = bd_next;
             uint32_t raw[4] = {raw_next[0], raw_next[1], raw_next[2], raw_next[3]};
             const uint32_t itn = it + n_wg * kScatterWaves;
-            if (itn < n_blocks) { bd_next = blocks[itn]; load_block_chars<AA>(seq, bd_next, lane, raw_next); }
+            if (itn < n_blocks) { bd_next = blocks[block_lo + itn]; load_block_chars<AA>(seq, bd_next, lane, raw_next); }
             encode_chars<AA>(l, raw, lane);
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 valid = valid && slot < limit;                          // beyond the stream: never probed
                 bk[r] = (uint32_t)(slot >> shift);
                 const uint32_t low = (q << shift) | ((uint32_t)slot & ((1u << shift) - 1u));
-                const uint32_t id = (it << 9) | ((uint32_t)r << 6) | (uint32_t)lane;
+                const uint32_t id = ((block_lo + it) << 9) | ((uint32_t)r << 6) | (uint32_t)lane;
                 e[r] = ((uint64_t)id << 32) | low;
                 if (valid) pend |= 1u << r;
             }

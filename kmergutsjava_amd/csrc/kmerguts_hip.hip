@@ -99,6 +99,8 @@ struct DevCache {
 struct kg_table {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // partitioned scan: tag / verify passes of one chunk overlap the next chunk's scatter
+    hipEvent_t pev[18] = {};            // [2c] chunk c scattered, [2c+1] chunk c probed (c < 8); [16],[17] fork / join
     bool own_entries = false;
     uint8_t *d_entries = nullptr;
     uint8_t *d_tags = nullptr;
@@ -175,6 +177,8 @@ int table_finish(kg_table *t)
     HIP_TRY(hipFree(d_occ));
     t->occupied = occ;
     for (auto &e : t->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : t->pev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
     return KG_OK;
 }
 
@@ -336,6 +340,9 @@ void kg_table_close(kg_table *t)
     t->cache.release_all();
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : t->pev)
+        if (e) (void)hipEventDestroy(e);
+    if (t->stream2) { (void)hipStreamSynchronize(t->stream2); (void)hipStreamDestroy(t->stream2); }
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
 }
@@ -375,7 +382,8 @@ struct Scratch {
     explicit Scratch(kg_table *tt) : t(tt) {}
     ~Scratch()
     {
-        (void)hipStreamSynchronize(t->stream);      // blocks go back to the cache only when the stream is idle
+        (void)hipStreamSynchronize(t->stream);      // blocks go back to the cache only when both streams are idle
+        if (t->stream2) (void)hipStreamSynchronize(t->stream2);
         for (void *p : ptrs) dfree(t, p);
     }
     void adopt(void *p) { ptrs.push_back(p); }
@@ -488,38 +496,41 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
     if (use_part) {
         constexpr uint32_t WIN = AA ? 64u : 384u;                                    // windows per block
         const uint32_t per_iter = kg::kScatterWaves;
+        // The batch is cut into chunks of blocks; chunk c+1 is scattered (stream) while chunk c is probed (stream2):
+        // the scatter pass is LDS/issue-bound with one 16-wave workgroup per CU, the tag pass is L2-bound with few
+        // registers and no LDS, so the two share the CUs.
+        uint32_t n_chunks_p = env_u32("KG_PART_CHUNKS", 4u);
+        if (n_chunks_p < 1) n_chunks_p = 1;
+        if (n_chunks_p > 8) n_chunks_p = 8;
+        while (n_chunks_p > 1 && nblocks / n_chunks_p < 64ull * 1024) n_chunks_p--;
+        const uint64_t chunk_blocks = ((nblocks + n_chunks_p - 1) / n_chunks_p + per_iter - 1) / per_iter * per_iter;
         uint32_t n_wg = env_u32("KG_PART_WGS", 256u);
-        if ((uint64_t)n_wg * per_iter > nblocks) n_wg = (uint32_t)((nblocks + per_iter - 1) / per_iter);
-        const uint64_t blocks_per_wg = ((nblocks + (uint64_t)n_wg * per_iter - 1) / ((uint64_t)n_wg * per_iter)) * per_iter;
+        if ((uint64_t)n_wg * per_iter > chunk_blocks) n_wg = (uint32_t)((chunk_blocks + per_iter - 1) / per_iter);
+        const uint64_t blocks_per_wg = ((chunk_blocks + (uint64_t)n_wg * per_iter - 1) / ((uint64_t)n_wg * per_iter)) * per_iter;
         // region capacity: the mean if every window were valid and hashed uniformly, plus 6 sigma, in 16-entry groups
         const double mean = (double)blocks_per_wg * WIN / (double)part_buckets * (env_u32("KG_PART_SLACK", 100u) / 100.0);
         const uint32_t cap = (uint32_t)(((uint64_t)(mean + 6.0 * std::sqrt(mean) + 32.0) + 15) / 16 * 16);
-        const uint64_t n_regions_total = (uint64_t)part_buckets * n_wg;
-        const uint32_t ovf_cap = env_u32("KG_PART_OVF_GROUPS", (uint32_t)std::min<uint64_t>(1u << 22, std::max<uint64_t>(4096, n_regions_total * cap / 16 / 64)));
+        const uint64_t n_regions_total = (uint64_t)part_buckets * n_wg;               // per chunk
+        const uint32_t ovf_cap = env_u32("KG_PART_OVF_GROUPS", (uint32_t)std::min<uint64_t>(1u << 22, std::max<uint64_t>(4096, n_regions_total * n_chunks_p * cap / 16 / 64)));
         uint64_t *d_ent = nullptr, *d_ovf_ent = nullptr;
         uint32_t *d_fill = nullptr, *d_ovf_bucket = nullptr, *d_next = nullptr, *d_ovfc = nullptr;
         unsigned long long *d_masks = nullptr;
-        if ((rc = sc.get(&d_ent, (size_t)(n_regions_total * cap)))) return rc;
-        if ((rc = sc.get(&d_fill, (size_t)n_regions_total))) return rc;
+        if ((rc = sc.get(&d_ent, (size_t)(n_regions_total * cap * n_chunks_p)))) return rc;
+        if ((rc = sc.get(&d_fill, (size_t)n_regions_total * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_ovf_ent, (size_t)ovf_cap * kg::kGroup))) return rc;
         if ((rc = sc.get(&d_ovf_bucket, (size_t)ovf_cap))) return rc;
-        if ((rc = sc.get(&d_next, (size_t)part_buckets + 8))) return rc;
+        const size_t next_stride = (size_t)part_buckets + 8;
+        if ((rc = sc.get(&d_next, next_stride * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_ovfc, 8))) return rc;
         if ((rc = sc.get(&d_masks, (size_t)n_rows))) return rc;
         unsigned long long *d_cursor = (unsigned long long *)(d_totals + 1);
         unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
         HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
-        HIP_TRY(hipMemsetAsync(d_ovfc, 0, 32, t->stream));
         HIP_TRY(hipMemsetAsync(d_masks, 0, n_rows * 8, t->stream));
         const size_t lds = kg::scatter_lds_bytes<AA>(part_buckets);
         HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipEventRecord(t->ev[1], t->stream));
-        hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
-                           d_blocks, (uint32_t)nblocks, t->limit, (uint64_t)t->num_sigs, t->magic, part_shift, part_buckets, cap,
-                           d_ent, d_fill, d_ovfc, ovf_cap, d_ovf_bucket, d_ovf_ent, d_ctr);
-        HIP_TRY(hipGetLastError());
         const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 4u) & ~7u;
-        uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio) + (uint64_t)(probe_grid + 64) * 4 * kg::kUChunk + 4096 +
+        uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio) + (uint64_t)(probe_grid + 64) * 4 * kg::kUChunk * n_chunks_p + 4096 +
                          kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         kg_hit *d_ulist = nullptr;
         uint32_t *d_cused = nullptr, *d_candused = nullptr;
@@ -527,12 +538,13 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         uint64_t n_chunks = 0;
         bool too_skewed = false;
         // candidates = fingerprint matches (hits + ~0.4 % of the probes): a little above the hit list
-        uint64_t ccap = ((uint64_t)((double)windows * (t->stage_ratio * 1.25 + 0.01)) + (uint64_t)probe_grid * 4 * kg::kUChunk +
+        uint64_t ccap = ((uint64_t)((double)windows * (t->stage_ratio * 1.25 + 0.01)) + (uint64_t)probe_grid * 4 * kg::kUChunk * n_chunks_p +
                          4096 + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         unsigned long long *d_ccursor = (unsigned long long *)(d_totals + 6);
         const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
         const uint32_t grab_unit = 256u * kg::kProbeN;
         const uint32_t probe_grab = (std::max(env_u32("KG_PROBE_GRAB", cap), grab_unit) + grab_unit - 1) / grab_unit * grab_unit;
+        HIP_TRY(hipEventRecord(t->ev[1], t->stream));
         for (int attempt = 0; attempt < 3; attempt++) {
             if ((rc = dalloc(t, (void **)&d_ulist, ucap * sizeof(kg_hit)))) return rc;
             if ((rc = dalloc(t, (void **)&d_cused, (ucap / kg::kUChunk + 1) * 4))) { sc.adopt(d_ulist); return rc; }
@@ -542,32 +554,49 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
             HIP_TRY(hipMemsetAsync(d_candused, 0, (ccap / kg::kUChunk + 1) * 4, t->stream));
             HIP_TRY(hipMemsetAsync(d_cursor, 0, 8, t->stream));
             HIP_TRY(hipMemsetAsync(d_ccursor, 0, 8, t->stream));
-            HIP_TRY(hipMemsetAsync(d_totals + 3, 0, 8, t->stream));      // slots_inspected of a re-run starts over
-            HIP_TRY(hipMemsetAsync(d_next, 0, ((size_t)part_buckets + 8) * 4, t->stream));
+            HIP_TRY(hipMemsetAsync(d_totals + 2, 0, 16, t->stream));      // both counters of a re-run start over
+            HIP_TRY(hipMemsetAsync(d_ovfc, 0, 32, t->stream));
+            HIP_TRY(hipMemsetAsync(d_next, 0, next_stride * n_chunks_p * 4, t->stream));
+            HIP_TRY(hipEventRecord(t->pev[16], t->stream));               // fork: stream2 starts behind the clears
+            HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[16], 0));
 #define KG_PROBE_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic
 #define KG_ULIST_ARGS d_ulist, d_cused, d_cursor, ucap, d_masks, d_ctr
-#define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, d_ent, d_fill, n_wg, cap, part_buckets, part_shift, probe_grab, d_next, d_cand, \
+            for (uint32_t c = 0; c < n_chunks_p; c++) {
+                const uint64_t lo = (uint64_t)c * chunk_blocks;
+                if (lo >= nblocks) break;
+                const uint32_t nb = (uint32_t)std::min<uint64_t>(chunk_blocks, nblocks - lo);
+                uint64_t *ent_c = d_ent + (uint64_t)c * n_regions_total * cap;
+                uint32_t *fill_c = d_fill + (uint64_t)c * n_regions_total;
+                uint32_t *next_c = d_next + (size_t)c * next_stride;
+                hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
+                                   d_blocks, (uint32_t)lo, nb, t->limit, (uint64_t)t->num_sigs, t->magic, part_shift, part_buckets,
+                                   cap, ent_c, fill_c, d_ovfc, ovf_cap, d_ovf_bucket, d_ovf_ent, d_ctr);
+                HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
+                HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
+#define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, d_cand, \
                     d_candused, d_ccursor, ccap, d_ctr
-            HIP_TRY(hipEventRecord(t->ev[5], t->stream));
+                if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, t->stream2, KG_TAG_ARGS);
+                else hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, t->stream2, KG_TAG_ARGS);
+#undef KG_TAG_ARGS
+            }
+            HIP_TRY(hipEventRecord(t->ev[5], t->stream));                 // all chunks scattered
+            // candidates of all chunks are verified once the last tag pass is done
             if (counters) {
-                hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, t->stream, KG_TAG_ARGS);
-                HIP_TRY(hipEventRecord(t->ev[6], t->stream));
-                hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, t->stream, KG_PROBE_ARGS, d_cand,
+                hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, t->stream2, KG_PROBE_ARGS, d_cand,
                                    d_candused, d_ccursor, ccap, KG_ULIST_ARGS);
-                hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(64), dim3(256), 0, t->stream, KG_PROBE_ARGS,
+                hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(64), dim3(256), 0, t->stream2, KG_PROBE_ARGS,
                                    d_ovf_bucket, d_ovf_ent, d_ovfc, ovf_cap, part_shift, KG_ULIST_ARGS);
             } else {
-                hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, t->stream, KG_TAG_ARGS);
-                HIP_TRY(hipEventRecord(t->ev[6], t->stream));
-                hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, t->stream, KG_PROBE_ARGS, d_cand,
+                hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, t->stream2, KG_PROBE_ARGS, d_cand,
                                    d_candused, d_ccursor, ccap, KG_ULIST_ARGS);
-                hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(64), dim3(256), 0, t->stream, KG_PROBE_ARGS,
+                hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(64), dim3(256), 0, t->stream2, KG_PROBE_ARGS,
                                    d_ovf_bucket, d_ovf_ent, d_ovfc, ovf_cap, part_shift, KG_ULIST_ARGS);
             }
-#undef KG_TAG_ARGS
 #undef KG_PROBE_ARGS
 #undef KG_ULIST_ARGS
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(t->pev[17], t->stream2));              // join
+            HIP_TRY(hipStreamWaitEvent(t->stream, t->pev[17], 0));
             HIP_TRY(hipEventRecord(t->ev[7], t->stream));
             st.scan_launches++;
             uint64_t h_cur = 0, h_ccur = 0;
@@ -576,24 +605,16 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
             HIP_TRY(hipMemcpyAsync(&h_ccur, d_ccursor, 8, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipMemcpyAsync(&h_ovf, d_ovfc, 4, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
-            if (getenv("KG_DEBUG")) {
-                std::vector<uint32_t> hf((size_t)n_regions_total);
-                (void)hipMemcpy(hf.data(), d_fill, hf.size() * 4, hipMemcpyDeviceToHost);
-                uint64_t sum = 0; uint32_t mx = 0, mn = ~0u; uint64_t full = 0;
-                for (uint32_t v : hf) { sum += v; mx = std::max(mx, v); mn = std::min(mn, v); full += v + 16 > cap; }
-                fprintf(stderr, "[kg] region fill: sum %llu, min %u, max %u, full regions %llu\n", (unsigned long long)sum, mn, mx,
-                        (unsigned long long)full);
-            }
             if (getenv("KG_DEBUG"))
-                fprintf(stderr, "[kg] partition attempt %d: overflow groups %u (cap %u), hit list %llu (cap %llu), candidates %llu (cap %llu), "
-                                "regions %llu x %u entries, %u buckets, shift %u, %u scatter workgroups\n",
-                        attempt, h_ovf, ovf_cap, (unsigned long long)h_cur, (unsigned long long)ucap, (unsigned long long)h_ccur,
+                fprintf(stderr, "[kg] partition attempt %d: %u chunks, overflow groups %u (cap %u), hit list %llu (cap %llu), candidates %llu "
+                                "(cap %llu), regions/chunk %llu x %u entries, %u buckets, shift %u, %u scatter workgroups\n",
+                        attempt, n_chunks_p, h_ovf, ovf_cap, (unsigned long long)h_cur, (unsigned long long)ucap, (unsigned long long)h_ccur,
                         (unsigned long long)ccap, (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg);
             if (h_ovf > ovf_cap) { too_skewed = true; break; }           // more overflow than provisioned: direct path
             n_chunks = h_cur / kg::kUChunk;
             if (h_cur <= ucap && h_ccur <= ccap) break;
             // a list was too small: now the exact need is known (masks are idempotent: the re-run sets the same bits)
-            dfree(t, d_ulist); dfree(t, d_cused); dfree(t, d_cand); dfree(t, d_candused);     // stream is idle here
+            dfree(t, d_ulist); dfree(t, d_cused); dfree(t, d_cand); dfree(t, d_candused);     // both streams are idle here
             d_ulist = nullptr; d_cused = nullptr; d_cand = nullptr; d_candused = nullptr;
             if (attempt == 2) return fail(KG_ERR_DEVICE, "hit list overflow after resize (internal error)");
             if (h_ccur > ccap) { ccap = h_ccur; ucap = std::max<uint64_t>(ucap, h_ccur); }     // hits <= candidates
@@ -754,9 +775,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
     HIP_TRY(hipEventElapsedTime(&ms, t->ev[3], t->ev[4])); st.ms_aggregate = ms;
     HIP_TRY(hipEventElapsedTime(&ms, t->ev[0], t->ev[4])); st.ms_total = ms;
     if (st.partitioned) {
+        // the passes of different chunks overlap: "scatter" = until the last chunk is scattered, "tail" = what is left
+        // of the tag / verify passes after that; ms_part_tag is kept for layout compatibility
         HIP_TRY(hipEventElapsedTime(&ms, t->ev[1], t->ev[5])); st.ms_part_scatter = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, t->ev[5], t->ev[6])); st.ms_part_tag = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, t->ev[6], t->ev[7])); st.ms_part_verify = ms;
+        st.ms_part_tag = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, t->ev[5], t->ev[7])); st.ms_part_verify = ms;
     }
     return KG_OK;
 }
