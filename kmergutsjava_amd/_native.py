@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkmerguts_hip.so")
+LIB_PATH = os.environ.get("KG_LIB_PATH") or os.path.join(HERE, "libkmerguts_hip.so")   # KG_LIB_PATH: tuning builds only
 
 KG_OK = 0
 KG_F_COUNTERS = 1

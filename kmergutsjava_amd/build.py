@@ -48,7 +48,7 @@ CLI = os.path.join(HERE, "kmer_guts")
 
 def build_cli(force: bool = False, verbose: bool = False) -> str:
     """The native command line (C++ over the C ABI): kmergutsjava_amd/kmer_guts."""
-    build_native(force, verbose)
+    build_native(False, verbose)
     src = os.path.join(CSRC, "kmer_guts_cli.cpp")
     if force or _stale(CLI, [src, os.path.join(ROOT, "include", "kmerguts_hip.h")]):
         cxx = shutil.which("g++") or shutil.which("hipcc")

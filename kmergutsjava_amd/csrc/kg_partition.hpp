@@ -79,21 +79,54 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     encode_init<AA>(l, lane);
     __syncthreads();
 
-    // one 128-byte group out of LDS: into the region, or onto the overflow list when the region is full
-    auto flush_group = [&](uint32_t b) {
-        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(buf + (size_t)b * kGroup);
-        const uint32_t rel = wrel[b];
-        ulonglong2 *dst = nullptr;
-        if (rel + kGroup <= cap) {
-            dst = reinterpret_cast<ulonglong2 *>(ent + ((uint64_t)b * n_wg + w) * cap + rel);
-            wrel[b] = rel + kGroup;
-        } else {
-            const uint32_t g = atomicAdd(ovf_cursor, 1u);
-            if (g < ovf_cap) { ovf_bucket[g] = b; dst = reinterpret_cast<ulonglong2 *>(ovf_ent + (uint64_t)g * kGroup); }
-        }
-        if (dst) {
+    // Flush: wave v owns the buckets [v * per_wave, (v + 1) * per_wave); one lane looks at one bucket; the wave then
+    // writes its full buffers eight at a time, eight lanes per 128-byte group (16 bytes each: one coalesced line per
+    // group instead of eight scattered 16-byte stores by one lane).  min_fill = kGroup: full buffers only;
+    // min_fill = 1: every non-empty buffer, padded with fillers (end of the kernel).
+    const uint32_t per_wave = (n_buckets + kScatterWaves - 1) / kScatterWaves;
+    auto flush_wave = [&](uint32_t min_fill) {
+        for (uint32_t b0 = (uint32_t)wave * per_wave; b0 < min((uint32_t)(wave + 1) * per_wave, n_buckets); b0 += 64) {
+            const uint32_t b = b0 + (uint32_t)lane;
+            const bool mine = b < min((uint32_t)(wave + 1) * per_wave, n_buckets);
+            const uint32_t c = mine ? cnt[b] : 0u;
+            unsigned long long dst_off = ~0ull;                       // entry index in ent (bit 62: in ovf_ent)
+            if (c >= min_fill && c > 0) {
+                if (c < kGroup)
+                    for (uint32_t k = c; k < kGroup; k++) buf[(size_t)b * kGroup + k] = kEntInvalid;
+                const uint32_t rel = wrel[b];
+                if (rel + kGroup <= cap) {
+                    dst_off = ((uint64_t)b * n_wg + w) * cap + rel;
+                    wrel[b] = rel + kGroup;
+                } else {
+                    const uint32_t g = atomicAdd(ovf_cursor, 1u);
+                    if (g < ovf_cap) { ovf_bucket[g] = b; dst_off = (1ull << 62) | ((uint64_t)g * kGroup); }
+                    else dst_off = ~0ull - 1;                         // dropped (the host falls back to direct probing)
+                }
+                cnt[b] = 0;
+            }
+            unsigned long long m = __ballot(dst_off != ~0ull);
+            wave_sync();                                             // the fillers above are read by other lanes below
+            while (m) {
+                // the next (up to) eight flushing lanes; lane group g = lane / 8 takes the g-th of them
+                int src_lane = -1;
+                unsigned long long mm = m;
 #pragma unroll
-            for (int k = 0; k < (int)kGroup / 2; k++) dst[k] = src[k];
+                for (int g = 0; g < 8; g++) {
+                    const int ln = mm ? __builtin_ctzll(mm) : -1;
+                    if (mm) mm &= mm - 1;
+                    if ((lane >> 3) == g) src_lane = ln;
+                }
+                m = mm;
+                const int sl = src_lane < 0 ? 0 : src_lane;
+                const uint32_t fb = (uint32_t)__shfl((int)b, sl);
+                const unsigned long long off = __shfl(dst_off, sl);
+                if (src_lane >= 0 && off != ~0ull - 1) {
+                    const uint32_t sub = (uint32_t)lane & 7u;
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(buf + (size_t)fb * kGroup + 2 * sub);
+                    uint64_t *base = (off >> 62) & 1 ? ovf_ent + (off & ~(1ull << 62)) : ent + off;
+                    *reinterpret_cast<ulonglong2 *>(base + 2 * sub) = v;
+                }
+            }
         }
     };
 
@@ -137,29 +170,22 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
         // re-inserts after the flush was tried: same time, and with 16 waves a quarter of the entries spill.)
         int more;
         do {
+            uint32_t at[ROWS];
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                if (pend & (1u << r)) {
-                    const uint32_t at = atomicAdd(&cnt[bk[r]], 1u);
-                    if (at < kGroup) { buf[(size_t)bk[r] * kGroup + at] = e[r]; pend &= ~(1u << r); }
-                }
-            }
+            for (int r = 0; r < ROWS; r++)                             // the LDS atomics of all rows in flight together
+                at[r] = (pend & (1u << r)) ? atomicAdd(&cnt[bk[r]], 1u) : kGroup;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++)
+                if (at[r] < kGroup) { buf[(size_t)bk[r] * kGroup + at[r]] = e[r]; pend &= ~(1u << r); }
             __syncthreads();
-            for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
-                if (cnt[b] >= kGroup) { flush_group(b); cnt[b] = 0; }
-            }
+            flush_wave(kGroup);
             more = __syncthreads_or(pend != 0);
         } while (more);
     }
     // partial groups, padded with fillers
-    for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
-        const uint32_t c = cnt[b];
-        if (c) {
-            for (uint32_t k = c; k < kGroup; k++) buf[(size_t)b * kGroup + k] = kEntInvalid;
-            flush_group(b);
-        }
-        fill[(uint64_t)b * n_wg + w] = wrel[b];
-    }
+    flush_wave(1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) fill[(uint64_t)b * n_wg + w] = wrel[b];
     for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
     if (lane == 0 && n_valid) atomicAdd(&ctr[0], n_valid);
 }
