@@ -11,13 +11,17 @@
 //   part_scatter_kernel  : encode every window once; entry -> 16-entry (128-byte) write-combining buffer of its
 //                          bucket in the workgroup's LDS -> the workgroup's over-allocated region of the bucket
 //                          (no counting pass, no per-entry global atomics; overflow list for skewed inputs)
-//   bucket_probe_kernel  : persistent workgroups; group x = blockIdx % 8 (XCD under round-robin placement,
-//                          speed only) walks the buckets b % 8 == x; 16-tag probe as in probe_n; a hit sets bit
+//   bucket_tag_kernel    : persistent workgroups; group x = blockIdx % 8 (XCD under round-robin placement,
+//                          speed only) walks the buckets b % 8 == x; per entry a 16-tag walk out of L2; a
+//                          fingerprint match becomes a 16-byte candidate record
+//   verify_kernel        : one lane per candidate: fetch the 24-byte record, compare the key; a hit sets bit
 //                          `lane` in the 64-bit mask of its (block,row) and appends {id, payload} to an
 //                          unordered list
+//   overflow_probe_kernel: the groups the scatter pass could not fit into their regions
 //   rows_from_masks      : popcount of the masks -> counts[] in container-major row order (then the usual
 //                          prefix sum)
-//   place_unordered      : unordered list -> hits[] at offs[row] + popcount(mask bits before the lane)
+//   row_info / place_unordered : unordered list -> hits[] at off[row] + popcount(mask bits before the lane)
+// The batch is processed in chunks of blocks: scatter of chunk c+1 overlaps the tag pass of chunk c (two streams).
 //
 // Entry (64 bit): low word = quotient << shift | slot_low, high word = id = block << 9 | row << 6 | lane;
 // value = quotient * numSigs + (bucket << shift | slot_low) exactly.
