@@ -54,6 +54,19 @@ typedef struct kg_params {
 #define KG_F_COUNTERS        1u  /* also count windows_valid / slots_inspected, slower     */
 #define KG_F_SKIP_AGGREGATE  2u  /* stop after the hit records (no CALL / OTU stage)                   */
 
+/* Event byte per hit record (kg_result_hit_events) and per container (kg_result_container_tail_events):
+ * what gatherHits (KGJ:457-514) did at that record, so that a host can print the -d stream (HIT, after-hit,
+ * after-call; KGJ:376-383, 406-409, 470-473, 498-501) by replaying the list contents without deciding anything.
+ * Order of the steps at one record: [RESET_BEFORE] -> [ACCEPTED] -> [RESET_AFTER]. */
+#define KG_EV_ACCEPTED      0x01u  /* the record was appended to the hits list (KGJ:496-497)                      */
+#define KG_EV_RESET_BEFORE  0x02u  /* gap rule (KGJ:477-484): the list was processed or cleared before the record */
+#define KG_EV_CALL_BEFORE   0x04u  /*   ... and that printed the container's next CALL                            */
+#define KG_EV_KEEP2_BEFORE  0x08u  /*   ... and the list kept its last two members (KGJ:441-449), else it is empty */
+#define KG_EV_RESET_AFTER   0x10u  /* pair rule (KGJ:503-508): processSetOfHits ran after the append step         */
+#define KG_EV_CALL_AFTER    0x20u
+#define KG_EV_KEEP2_AFTER   0x40u
+#define KG_EV_TAIL_CALL     0x01u  /* container byte: the final flush (KGJ:511-513) printed a CALL                */
+
 /* Binary records.  Text formatting (KGJ:398-404, 518-548) stays in host code. */
 typedef struct kg_hit {          /* replaces class Hit (KGJ:1213-1219) + its HitContainer id (KGJ:1262-1266) */
     uint32_t container;          /* running container index: seq*6 + {+0,+1,+2,-0,-1,-2} (DNA) or seq (AA), KGJ:907-911 */
@@ -135,6 +148,8 @@ const int64_t *kg_result_container_hit_start(kg_result *r);  /* n_containers + 1
 const kg_call *kg_result_calls(kg_result *r);                /* n_calls, in the reference's emission order     */
 const int64_t *kg_result_container_call_start(kg_result *r); /* n_containers + 1                              */
 const kg_otu  *kg_result_otu(kg_result *r);                  /* n_seqs                                        */
+const uint8_t *kg_result_hit_events(kg_result *r);           /* n_hits bytes of KG_EV_*                        */
+const uint8_t *kg_result_container_tail_events(kg_result *r);/* n_containers bytes of KG_EV_TAIL_*             */
 /* Device views (valid until kg_result_free) for callers that keep working in HBM. */
 const void    *kg_result_device_hits(const kg_result *r);
 const void    *kg_result_device_calls(const kg_result *r);

@@ -64,6 +64,8 @@ public interface KmerGutsHip extends Library {
     Pointer kg_result_calls(Pointer result);                 // kg_call[n_calls] 24 B each
     Pointer kg_result_container_call_start(Pointer result);  // int64[n_containers + 1]
     Pointer kg_result_otu(Pointer result);                   // kg_otu[n_seqs]   44 B each
+    Pointer kg_result_hit_events(Pointer result);            // byte[n_hits]        KG_EV_* (for the -d stream)
+    Pointer kg_result_container_tail_events(Pointer result); // byte[n_containers]  KG_EV_TAIL_CALL
     Pointer kg_result_device_hits(Pointer result);
     Pointer kg_result_device_calls(Pointer result);
     Pointer kg_result_device_otu(Pointer result);

@@ -22,9 +22,14 @@ KG_OI_BUFSZ = 5
 EXPORTS = (
     "kg_table_open", "kg_table_from_memory", "kg_table_from_device", "kg_table_info", "kg_table_close",
     "kg_scan", "kg_scan_device", "kg_result_stats", "kg_result_hits", "kg_result_container_hit_start",
-    "kg_result_calls", "kg_result_container_call_start", "kg_result_otu", "kg_result_device_hits",
-    "kg_result_device_calls", "kg_result_device_otu", "kg_result_free", "kg_last_error", "kg_version",
+    "kg_result_calls", "kg_result_container_call_start", "kg_result_otu", "kg_result_hit_events",
+    "kg_result_container_tail_events", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu", "kg_result_free", "kg_last_error", "kg_version",
 )
+
+# event bits (include/kmerguts_hip.h KG_EV_*)
+EV_ACCEPTED, EV_RESET_BEFORE, EV_CALL_BEFORE, EV_KEEP2_BEFORE = 0x01, 0x02, 0x04, 0x08
+EV_RESET_AFTER, EV_CALL_AFTER, EV_KEEP2_AFTER = 0x10, 0x20, 0x40
+EV_TAIL_CALL = 0x01
 
 HIT_DTYPE = np.dtype([("container", "<u4"), ("from0InProt", "<i4"), ("oI", "<i4"),
                       ("avgOffFromEnd", "<i4"), ("fI", "<i4"), ("functionWt", "<f4")])
@@ -82,8 +87,8 @@ def load() -> C.CDLL:
     lib.kg_scan_device.argtypes = [vp, C.POINTER(KgParams), vp, vp, C.c_int64, C.POINTER(vp)]
     lib.kg_result_stats.argtypes = [vp, C.POINTER(KgStats)]
     for name in ("kg_result_hits", "kg_result_container_hit_start", "kg_result_calls",
-                 "kg_result_container_call_start", "kg_result_otu", "kg_result_device_hits",
-                 "kg_result_device_calls", "kg_result_device_otu"):
+                 "kg_result_container_call_start", "kg_result_otu", "kg_result_hit_events",
+                 "kg_result_container_tail_events", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu"):
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = vp
     lib.kg_result_free.argtypes = [vp]

@@ -18,6 +18,12 @@
 //
 // Calls per container are counted first (EMIT = false), prefix-summed, then written (EMIT = true)
 // so that calls[] is in the reference's emission order without atomics.
+//
+// The counting pass also leaves one event byte per record (KG_EV_* in kmerguts_hip.h) and one per
+// container: what the machine did at that record (appended it, reset the list before / after it,
+// whether that reset printed a CALL and whether it kept the last two members).  Bit 0 is the
+// "accepted" byte above; the rest lets the host print the reference's -d stream (HIT / after-hit /
+// after-call, KGJ:376-383, 406-409, 470-473, 498-501) without re-deciding anything.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -45,8 +51,9 @@ __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_read
 // processSetOfHits (KGJ:385-455) on the list [s.lo .. s.last].  chunk grid is anchored at `begin`
 // so that the chunk the caller is working on (cur_base, membership bits cur_mask) can be taken from
 // registers instead of acc[].
+// returns bit 0: a CALL was made, bit 1: the last two members were kept
 template <bool EMIT>
-__device__ __forceinline__ void process_set(const kg_hit *__restrict__ h, const uint8_t *__restrict__ acc, uint32_t begin,
+__device__ __forceinline__ uint32_t process_set(const kg_hit *__restrict__ h, const uint8_t *__restrict__ acc, uint32_t begin,
                                             const AggParams &p, AggState &s, uint32_t cur_base, uint64_t cur_mask,
                                             uint32_t container, uint32_t call_at, kg_call *calls, CallSpan *spans,
                                             bool allow_carry)
@@ -65,7 +72,7 @@ __device__ __forceinline__ void process_set(const kg_hit *__restrict__ h, const 
         if (in) {
             fI = h[i].fI;
             wt = h[i].functionWt;
-            mem = (b == cur_base) ? ((cur_mask >> lane) & 1ull) != 0 : acc[i] != 0;
+            mem = (b == cur_base) ? ((cur_mask >> lane) & 1ull) != 0 : (acc[i] & KG_EV_ACCEPTED) != 0;
         }
         uint64_t m = __ballot(in && mem && fI == s.currentFI);
         if (m) {
@@ -79,7 +86,9 @@ __device__ __forceinline__ void process_set(const kg_hit *__restrict__ h, const 
             }
         }
     }
+    uint32_t what = 0;
     if (fICount >= p.min_hits && weighted >= (float)p.min_weighted_hits) {      // KGJ:397
+        what = 1;
         if (EMIT && lane == 0) {
             kg_call c;
             c.container = container;
@@ -97,15 +106,35 @@ __device__ __forceinline__ void process_set(const kg_hit *__restrict__ h, const 
         s.currentFI = s.last_fI;
         s.lo = s.prev;
         s.cnt = 2;
+        what |= 2;
     } else {
         s.cnt = 0;
     }
+    return what;
 }
+
+// per-chunk event masks (wave-uniform; bit k = record base + k)
+struct EvMasks {
+    uint64_t pb, pb_call, pb_keep, pa, pa_call, pa_keep;
+    __device__ __forceinline__ void before(int k, uint32_t what)
+    {
+        pb |= 1ull << k;
+        pb_call |= (uint64_t)(what & 1) << k;
+        pb_keep |= (uint64_t)((what >> 1) & 1) << k;
+    }
+    __device__ __forceinline__ void after(int k, uint32_t what)
+    {
+        pa |= 1ull << k;
+        pa_call |= (uint64_t)(what & 1) << k;
+        pa_keep |= (uint64_t)((what >> 1) & 1) << k;
+    }
+};
 
 template <bool EMIT>
 __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restrict__ hits, const int64_t *__restrict__ chs,
-                                                         uint32_t n_cont, AggParams p, uint8_t *acc, uint32_t *call_cnt,
-                                                         const uint32_t *call_off, kg_call *calls, CallSpan *spans)
+                                                         uint32_t n_cont, AggParams p, uint8_t *acc, uint8_t *tail_ev,
+                                                         uint32_t *call_cnt, const uint32_t *call_off, kg_call *calls,
+                                                         CallSpan *spans)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t c = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -128,6 +157,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
         int32_t pos = 0, fI = 0, avg = 0;
         if (lane < n) { pos = hits[i].from0InProt; fI = hits[i].fI; avg = hits[i].avgOffFromEnd; }
         uint64_t accmask;
+        EvMasks em = {0, 0, 0, 0, 0, 0};
 
         // the fast path needs every record of the chunk to be accepted and the list's last member to be
         // the record just before the chunk (after a cap overflow the list can end far behind)
@@ -154,20 +184,22 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                 const int32_t fk = rl(fI, k);
                 const uint32_t ik = base + (uint32_t)k;
                 if (s.cnt > 0 && ((gapm >> k) & 1)) {                                   // KGJ:477-484
+                    uint32_t what = 0;
                     if (s.cnt >= p.min_hits) {
                         s.last = ik - 1;
                         // no carry is possible here: a pair of equal, non-current fI at the end of the list
                         // would have fired the pair rule when its second record was appended
-                        process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, false);
+                        what = process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, false);
                     } else {
                         s.cnt = 0;
                     }
+                    em.before(k, what);
                 }
                 if (s.cnt == 0) { s.currentFI = fk; s.lo = ik; }                         // KGJ:486-488
                 s.cnt++;                                                                 // KGJ:496-497
                 if (s.cnt > 1 && s.currentFI != fk && ((eqm >> k) & 1)) {                // KGJ:503-508
                     s.last = ik; s.prev = ik - 1; s.last_fI = fk; s.prev_fI = fk;
-                    process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true);
+                    em.after(k, process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true));
                 }
                 k0 = k + 1;
             }
@@ -187,10 +219,12 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                 const int32_t pk = rl(pos, k), fk = rl(fI, k), ak = rl(avg, k);
                 const uint32_t ik = base + (uint32_t)k;
                 if (s.cnt > 0 && (int32_t)((uint32_t)s.last_pos + (uint32_t)p.max_gap) < pk) {      // KGJ:477-484
+                    uint32_t what = 0;
                     if (s.cnt >= p.min_hits)
-                        process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true);
+                        what = process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true);
                     else
                         s.cnt = 0;
+                    em.before(k, what);
                 }
                 if (s.cnt == 0) s.currentFI = fk;                                                    // KGJ:486-488
                 bool ok = !p.order_constraint || s.cnt == 0;
@@ -208,20 +242,30 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                         accmask |= 1ull << k;
                     }
                     if (s.cnt > 1 && s.currentFI != fk && s.prev_fI == s.last_fI)                    // KGJ:503-508
-                        process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true);
+                        em.after(k, process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true));
                 }
             }
         }
-        if (!EMIT && lane < n) acc[i] = (uint8_t)((accmask >> lane) & 1ull);
+        if (!EMIT && lane < n) {
+            uint32_t e = (uint32_t)((accmask >> lane) & 1ull) * KG_EV_ACCEPTED;
+            e |= (uint32_t)((em.pb >> lane) & 1ull) * KG_EV_RESET_BEFORE;
+            e |= (uint32_t)((em.pb_call >> lane) & 1ull) * KG_EV_CALL_BEFORE;
+            e |= (uint32_t)((em.pb_keep >> lane) & 1ull) * KG_EV_KEEP2_BEFORE;
+            e |= (uint32_t)((em.pa >> lane) & 1ull) * KG_EV_RESET_AFTER;
+            e |= (uint32_t)((em.pa_call >> lane) & 1ull) * KG_EV_CALL_AFTER;
+            e |= (uint32_t)((em.pa_keep >> lane) & 1ull) * KG_EV_KEEP2_AFTER;
+            acc[i] = (uint8_t)e;
+        }
         carry_pos = rl(pos, n - 1);
         carry_fI = rl(fI, n - 1);
         tail_base = base;
         tail_mask = accmask;
     }
+    uint32_t tail = 0;
     if (s.cnt >= p.min_hits) {                                                                       // KGJ:511-513
-        process_set<EMIT>(hits, acc, begin, p, s, tail_base, tail_mask, c, call_at, calls, spans, true);
+        tail = process_set<EMIT>(hits, acc, begin, p, s, tail_base, tail_mask, c, call_at, calls, spans, true) & 1u;
     }
-    if (!EMIT && lane == 0) call_cnt[c] = s.ncalls;
+    if (!EMIT && lane == 0) { call_cnt[c] = s.ncalls; tail_ev[c] = (uint8_t)tail; }
 }
 
 // ccs[c] = call_off[c] widened, plus sentinel
@@ -254,7 +298,7 @@ __global__ __launch_bounds__(256) void otu_wave_kernel(const kg_hit *__restrict_
             const uint32_t i = b + lane;
             bool vote = false;
             int32_t o = 0;
-            if (i <= sp.last_hit) { vote = acc[i] != 0 && hits[i].fI == fI; o = hits[i].oI; }
+            if (i <= sp.last_hit) { vote = (acc[i] & KG_EV_ACCEPTED) != 0 && hits[i].fI == fI; o = hits[i].oI; }
             uint64_t m = __ballot(vote);
             while (m) {
                 const int k = __builtin_ctzll(m);

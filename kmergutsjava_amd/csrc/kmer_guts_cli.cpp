@@ -326,6 +326,12 @@ int main(int argc, char **argv)
         for (int64_t k : first_order) order.push_back(last_of[fa.ids[(size_t)k]]);
 
         long long t2 = now_ms();
+        if (o.debug) {                                             // KGJ:951-954
+            int64_t ns = 0, es = 0, ver = 0, occ = 0;
+            check(kg_table_info(tab, &ns, &es, &ver, &occ));
+            out.put("Kmer-table info: numSigs=" + std::to_string(ns) + ", entrySize=" + std::to_string(es) +
+                    ", version=" + std::to_string(ver) + "\n");
+        }
         kg_params p{};
         p.aa = o.aa; p.order_constraint = o.order_constraint; p.min_hits = o.min_hits;
         p.min_weighted_hits = o.min_weighted_hits; p.max_gap = o.max_gap; p.flags = 0;
@@ -361,6 +367,14 @@ int main(int argc, char **argv)
             const int64_t *ccs = kg_result_container_call_start(res);
             const kg_otu *otu = kg_result_otu(res);
             if (!ccs || !otu) die(std::string("libkmerguts_hip: ") + kg_last_error());
+            const kg_hit *hits = nullptr;                          // -d: hit records + what gatherHits did at each
+            const int64_t *chs = nullptr;
+            const uint8_t *ev = nullptr, *tail = nullptr;
+            if (o.debug) {
+                hits = kg_result_hits(res); chs = kg_result_container_hit_start(res);
+                ev = kg_result_hit_events(res); tail = kg_result_container_tail_events(res);
+                if (!hits || !chs || !ev || !tail) die(std::string("libkmerguts_hip: ") + kg_last_error());
+            }
             // with one batch (inputs up to ~1.5 Gbp) the info lines sit exactly where the reference prints them
             if (at == 0) info("Lookup time: " + std::to_string(now_ms() - t2) + " ms.");
             long long t3 = now_ms();
@@ -374,14 +388,51 @@ int main(int argc, char **argv)
                     if (!o.aa)                                                                         // KGJ:545
                         r += "TRANSLATION\t" + id + "\t" + std::to_string(len) + "\t" + (f < 3 ? "+" : "-") + "\t" +
                              std::to_string(f % 3) + "\n";
-                    for (int64_t c = ccs[j * per + f]; c < ccs[j * per + f + 1]; c++) {               // KGJ:398-404
+                    const int64_t cont = (int64_t)j * per + f;
+                    auto put_call = [&](int64_t c) {                                                  // KGJ:398-404
                         const kg_call &cl = calls[c];
                         if (cl.fI < 0 || (size_t)cl.fI >= functions.size())
                             die("Index: " + std::to_string(cl.fI) + ", Size: " + std::to_string(functions.size()));
                         format_java_f(cl.weightedHits, 6, num, sizeof num);
                         r += "CALL\t" + std::to_string(cl.start) + "\t" + std::to_string(cl.end) + "\t" + std::to_string(cl.count) +
                              "\t" + std::to_string(cl.fI) + "\t" + functions[(size_t)cl.fI] + "\t" + num + "\n";
+                    };
+                    if (!o.debug) {
+                        for (int64_t c = ccs[cont]; c < ccs[cont + 1]; c++) put_call(c);
+                        continue;
                     }
+                    // -d stream (KGJ:470-473 HIT, 498-501 after-hit, 406-409 after-call, displayHits KGJ:376-383).
+                    // Nothing is decided here: the event bytes say when the reference's hits list grew, was
+                    // processed, kept its last two members or was emptied.
+                    std::vector<int64_t> live;
+                    int64_t nxt = ccs[cont];
+                    auto show = [&](const char *tag) {
+                        r += tag;
+                        r += "hits: ";
+                        for (int64_t i : live) {
+                            format_java_f(hits[i].functionWt, 6, num, sizeof num);
+                            r += std::to_string(hits[i].from0InProt) + "/" + num + "/" + std::to_string(hits[i].fI) + " ";
+                        }
+                        r += "\n";
+                    };
+                    auto reset = [&](bool called, bool keep2) {
+                        if (called) { put_call(nxt++); show("after-call: "); }
+                        if (keep2 && live.size() >= 2) live.erase(live.begin(), live.end() - 2);
+                        else live.clear();
+                    };
+                    for (int64_t i = chs[cont]; i < chs[cont + 1]; i++) {
+                        const kg_hit &h = hits[i];
+                        const uint8_t e = ev[i];
+                        format_java_f(h.functionWt, 3, num, sizeof num);
+                        r += "HIT\t" + std::to_string(h.from0InProt) + "\t0\t" + std::to_string(h.avgOffFromEnd) + "\t" +
+                             std::to_string(h.fI) + "\t" + num + "\t" + std::to_string(h.oI) + "\n";
+                        if (e & KG_EV_RESET_BEFORE) reset(e & KG_EV_CALL_BEFORE, e & KG_EV_KEEP2_BEFORE);
+                        if (e & KG_EV_ACCEPTED) { live.push_back(i); show("after-hit: "); }
+                        if (e & KG_EV_RESET_AFTER) reset(e & KG_EV_CALL_AFTER, e & KG_EV_KEEP2_AFTER);
+                        if (r.size() > (4u << 20)) { out.put(r); r.clear(); }
+                    }
+                    if (tail[cont] & KG_EV_TAIL_CALL) reset(true, false);
+                    if (nxt != ccs[cont + 1]) die("event bytes and CALL records disagree");
                 }
                 r += "OTU-COUNTS\t" + id + "[" + std::to_string(len) + "]";                          // KGJ:518-522
                 for (int k2 = 0; k2 < otu[j].n; k2++) r += "\t" + std::to_string(otu[j].count[k2]) + "-" + std::to_string(otu[j].oI[k2]);

@@ -123,8 +123,10 @@ struct kg_result {
     kg_call *d_calls = nullptr;
     int64_t *d_ccs = nullptr;
     kg_otu *d_otu = nullptr;
+    uint8_t *d_ev = nullptr, *d_tail_ev = nullptr;   // KG_EV_* per hit / per container
     // host copies (lazy), in pinned memory so the copy runs at PCIe rate
-    void *h_hits = nullptr, *h_chs = nullptr, *h_ccs = nullptr, *h_calls = nullptr, *h_otu = nullptr;
+    void *h_hits = nullptr, *h_chs = nullptr, *h_ccs = nullptr, *h_calls = nullptr, *h_otu = nullptr, *h_ev = nullptr,
+         *h_tail_ev = nullptr;
 };
 
 namespace {
@@ -354,8 +356,9 @@ void kg_result_free(kg_result *r)
     if (t) {
         // a result is only handed out after its scan has synchronised the stream
         dfree(t, r->d_hits); dfree(t, r->d_chs); dfree(t, r->d_calls); dfree(t, r->d_ccs); dfree(t, r->d_otu);
+        dfree(t, r->d_ev); dfree(t, r->d_tail_ev);
     }
-    for (void *h : {r->h_hits, r->h_chs, r->h_ccs, r->h_calls, r->h_otu})
+    for (void *h : {r->h_hits, r->h_chs, r->h_ccs, r->h_calls, r->h_otu, r->h_ev, r->h_tail_ev})
         if (h) (void)hipHostFree(h);
     delete r;
 }
@@ -734,8 +737,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         kg::AggParams ap;
         ap.min_hits = p->min_hits; ap.min_weighted_hits = p->min_weighted_hits;
         ap.max_gap = p->max_gap; ap.order_constraint = p->order_constraint ? 1 : 0;
-        uint8_t *d_acc = nullptr; uint32_t *d_ccnt = nullptr, *d_coff = nullptr; kg::CallSpan *d_spans = nullptr;
-        if ((rc = sc.get(&d_acc, n_hits))) return rc;
+        uint32_t *d_ccnt = nullptr, *d_coff = nullptr; kg::CallSpan *d_spans = nullptr;
+        if ((rc = dalloc(t, (void **)&res->d_ev, n_hits))) return rc;
+        if ((rc = dalloc(t, (void **)&res->d_tail_ev, n_cont))) return rc;
+        uint8_t *d_acc = res->d_ev;
         if ((rc = sc.get(&d_ccnt, n_cont))) return rc;
         if ((rc = sc.get(&d_coff, n_cont))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_ccs, (n_cont + 1) * 8))) return rc;
@@ -743,7 +748,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         uint32_t cgrid = (uint32_t)((n_cont + 3) / 4);           // one wave per container
         if (n_cont) {
             hipLaunchKernelGGL((kg::calls_wave_kernel<false>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
-                               (uint32_t)n_cont, ap, d_acc, d_ccnt, (const uint32_t *)nullptr, (kg_call *)nullptr,
+                               (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, (const uint32_t *)nullptr, (kg_call *)nullptr,
                                (kg::CallSpan *)nullptr);
             HIP_TRY(hipGetLastError());
         }
@@ -756,7 +761,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         if ((rc = sc.get(&d_spans, n_calls))) return rc;
         if (n_cont && n_calls) {
             hipLaunchKernelGGL((kg::calls_wave_kernel<true>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
-                               (uint32_t)n_cont, ap, d_acc, d_ccnt, d_coff, res->d_calls, d_spans);
+                               (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, d_coff, res->d_calls, d_spans);
         }
         hipLaunchKernelGGL(kg::call_starts_kernel, dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream, d_coff,
                            n_cont, d_totals + 4, res->d_ccs);
@@ -886,6 +891,18 @@ const kg_otu *kg_result_otu(kg_result *r)
     if (!r) return nullptr;
     if (!r->d_otu) { g_err = "OTU votes not computed (KG_F_SKIP_AGGREGATE)"; return nullptr; }
     return host_view(r, r->h_otu, r->d_otu, (size_t)r->st.n_seqs);
+}
+const uint8_t *kg_result_hit_events(kg_result *r)
+{
+    if (!r) return nullptr;
+    if (!r->d_ev) { g_err = "events not computed (KG_F_SKIP_AGGREGATE)"; return nullptr; }
+    return host_view(r, r->h_ev, r->d_ev, (size_t)r->st.n_hits);
+}
+const uint8_t *kg_result_container_tail_events(kg_result *r)
+{
+    if (!r) return nullptr;
+    if (!r->d_tail_ev) { g_err = "events not computed (KG_F_SKIP_AGGREGATE)"; return nullptr; }
+    return host_view(r, r->h_tail_ev, r->d_tail_ev, (size_t)r->st.n_containers);
 }
 const void *kg_result_device_hits(const kg_result *r) { return r ? r->d_hits : nullptr; }
 const void *kg_result_device_calls(const kg_result *r) { return r ? r->d_calls : nullptr; }

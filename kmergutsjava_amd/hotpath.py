@@ -69,6 +69,15 @@ class ScanResult:
         lib = self._need()
         return N.view(lib.kg_result_otu(self._h), self.stats["n_seqs"], N.OTU_DTYPE)
 
+    def hit_events(self) -> np.ndarray:
+        """One KG_EV_* byte per hit record: what gatherHits did there (for the -d stream)."""
+        lib = self._need()
+        return N.view(lib.kg_result_hit_events(self._h), self.stats["n_hits"], np.dtype("u1"))
+
+    def container_tail_events(self) -> np.ndarray:
+        lib = self._need()
+        return N.view(lib.kg_result_container_tail_events(self._h), self.stats["n_containers"], np.dtype("u1"))
+
     def device_hits_ptr(self) -> int:
         return self._need().kg_result_device_hits(self._h) or 0
 

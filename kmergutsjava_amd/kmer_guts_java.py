@@ -15,7 +15,9 @@ GPU, run() raises.
 Known, documented deviations from the reference's behaviour:
   * the progress lines "Processed: NN%, time=..." of the table stream (KGJ:1019-1025) are not
     printed: the table is not streamed;
-  * -d prints the info lines but not the HIT / after-hit / after-call debug stream (SURVEY 8f item 3);
+  * -d: the HIT / after-hit / after-call stream is printed (from the library's event bytes), and so are
+    the info lines except "Kmers found: N (pos-count=M)" and the progress lines, which describe the
+    reference's table stream (KGJ:1019-1032);
   * -t / -l: the reference's switch falls through to "Unknown parameter" for both (KGJ:605-611);
     this mirror does the same (message + usage, then carries on, KGJ:616-647);
   * input beyond 20 M k-mers: the reference silently drops queries in its external merge
@@ -33,6 +35,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 
 import numpy as np
 
+from . import _native as N
 from .hotpath import Params, SignatureTable
 
 _WS = " \t\n\x0b\x0c\r\x1c\x1d\x1e\x1f"      # what String.trim() strips is every char <= ' ' ; see _trim
@@ -264,6 +267,8 @@ class KmerGutsJava:
         order = [last_of[name] for name in last_of]
 
         t2 = time.time()
+        if self.debug:                                            # KGJ:951-954
+            pw.write("Kmer-table info: numSigs=%(numSigs)d, entrySize=%(entrySize)d, version=%(version)d\n" % tab.info())
         params = Params(aa=self.aa, order_constraint=self.orderConstraint, min_hits=self.minHits,
                         min_weighted_hits=self.minWeightedHits, max_gap=self.maxGap)
         per = 1 if self.aa else 6
@@ -281,9 +286,13 @@ class KmerGutsJava:
             buf = np.frombuffer(b"".join(seqs[k] for k in batch), dtype=np.uint8)
             with tab.scan(buf, off, params) as r:
                 calls, ccs, otu = r.calls(), r.container_call_start(), r.otu()
+                if self.debug:      # -d: the hit records and what gatherHits did at each of them
+                    hits, chs, ev, tail = r.hits(), r.container_hit_start(), r.hit_events(), r.container_tail_events()
                 self.last_stats.append(r.stats)
             for j, k in enumerate(batch):
-                results[k] = ([calls[ccs[j * per + f]:ccs[j * per + f + 1]] for f in range(per)], otu[j])
+                cs = range(j * per, j * per + per)
+                dbg = [(hits[chs[c]:chs[c + 1]], ev[chs[c]:chs[c + 1]], int(tail[c])) for c in cs] if self.debug else None
+                results[k] = ([calls[ccs[c]:ccs[c + 1]] for c in cs], otu[j], dbg)
             batch, size = [], 0
 
         for k in order:
@@ -296,36 +305,86 @@ class KmerGutsJava:
 
         t3 = time.time()
         for k in order:
-            calls, otu = results[k]
-            self.write_record(pw, ids[k], len(seqs[k]), calls, otu, function_array)
+            calls, otu, dbg = results[k]
+            self.write_record(pw, ids[k], len(seqs[k]), calls, otu, function_array, dbg)
         pw.flush()
         self._info("Grouping time: %d ms." % int((time.time() - t3) * 1000), pw, stdout)
 
-    def write_record(self, pw, name: str, ln: int, calls_per_container, otu, function_array) -> None:
+    def write_record(self, pw, name: str, ln: int, calls_per_container, otu, function_array, debug_per_container=None) -> None:
         """The report of one sequence: processSeq / processAASeq + tabulateOtuDataForContig
-        (KGJ:526-558, 516-524).  calls_per_container: 1 (protein) or 6 (+0 +1 +2 -0 -1 -2) CALL record arrays."""
+        (KGJ:526-558, 516-524).  calls_per_container: 1 (protein) or 6 (+0 +1 +2 -0 -1 -2) CALL record arrays;
+        debug_per_container (with -d): (hit records, event bytes, tail event) per container."""
         w = pw.write
+
+        def container(f):
+            if debug_per_container is None:
+                self._print_calls(calls_per_container[f], function_array, w)
+            else:
+                self._print_debug_stream(calls_per_container[f], function_array, w, *debug_per_container[f])
+
         if self.aa:
             w("PROTEIN-ID\t%s\t%d\n" % (name, ln))                              # KGJ:529
-            self._print_calls(calls_per_container[0], function_array, w)
+            container(0)
         else:
             w("processing %s[%d]\n" % (name, ln))                               # KGJ:541
             for f in range(6):
                 w("TRANSLATION\t%s\t%d\t%s\t%d\n" % (name, ln, "+-"[f // 3], f % 3))   # KGJ:545
-                self._print_calls(calls_per_container[f], function_array, w)
+                container(f)
         w("OTU-COUNTS\t%s[%d]" % (name, ln))                                    # KGJ:518-522
         for j in range(int(otu["n"])):
             w("\t%d-%d" % (int(otu["count"][j]), int(otu["oI"][j])))
         w("\n")
 
     @staticmethod
+    def _print_call(c, function_array, w) -> None:                                  # KGJ:398-404
+        fi = int(c["fI"])
+        if fi < 0 or fi >= len(function_array):
+            raise IndexError("Index: %d, Size: %d" % (fi, len(function_array)))      # functionArray.get() throws
+        w("CALL\t%d\t%d\t%d\t%d\t%s\t%s\n" % (int(c["start"]), int(c["end"]), int(c["count"]), fi,
+                                             function_array[fi], java_format_f(c["weightedHits"])))
+
+    @staticmethod
     def _print_calls(calls, function_array, w) -> None:
-        for c in calls:                                                             # KGJ:398-404
-            fi = int(c["fI"])
-            if fi < 0 or fi >= len(function_array):
-                raise IndexError("Index: %d, Size: %d" % (fi, len(function_array)))  # functionArray.get() throws
-            w("CALL\t%d\t%d\t%d\t%d\t%s\t%s\n" % (int(c["start"]), int(c["end"]), int(c["count"]), fi,
-                                                 function_array[fi], java_format_f(c["weightedHits"])))
+        for c in calls:
+            KmerGutsJava._print_call(c, function_array, w)
+
+    @staticmethod
+    def _print_debug_stream(calls, function_array, w, hits, events, tail) -> None:
+        """The -d text of one container (KGJ:470-473 HIT, 498-501 after-hit, 406-409 after-call, displayHits
+        KGJ:376-383).  Nothing is decided here: the event bytes written by the aggregation kernel say when the
+        hits list grew, was processed, kept its last two members or was emptied; this only prints."""
+        live: List[int] = []                  # indices (into hits) of the reference's "hits" list
+        nxt = 0
+
+        def show(tag):
+            w(tag + "hits: ")
+            for i in live:
+                h = hits[i]
+                w("%d/%s/%d " % (int(h["from0InProt"]), java_format_f(h["functionWt"]), int(h["fI"])))
+            w("\n")
+
+        def reset(called, keep2):
+            nonlocal nxt, live
+            if called:
+                KmerGutsJava._print_call(calls[nxt], function_array, w)
+                nxt += 1
+                show("after-call: ")
+            live = live[-2:] if keep2 else []
+
+        for i in range(len(hits)):
+            h, e = hits[i], int(events[i])
+            w("HIT\t%d\t%d\t%d\t%d\t%s\t%d\n" % (int(h["from0InProt"]), 0, int(h["avgOffFromEnd"]), int(h["fI"]),
+                                                  java_format_f(h["functionWt"], 3), int(h["oI"])))
+            if e & N.EV_RESET_BEFORE:
+                reset(e & N.EV_CALL_BEFORE, e & N.EV_KEEP2_BEFORE)
+            if e & N.EV_ACCEPTED:
+                live.append(i)
+                show("after-hit: ")
+            if e & N.EV_RESET_AFTER:
+                reset(e & N.EV_CALL_AFTER, e & N.EV_KEEP2_AFTER)
+        if tail & N.EV_TAIL_CALL:
+            reset(True, False)
+        assert nxt == len(calls), "event bytes and CALL records disagree"
 
     # ---- main (KGJ:560-654) ----
     USAGE = (

@@ -450,22 +450,32 @@ static int hit_pos_cmp(const void *a, const void *b)
     return 0;
 }
 
-/* KGJ:457-514 gatherHits on hits already sorted by from0InProt */
+/* KGJ:457-514 gatherHits on hits already sorted by from0InProt.
+ * trace (n bytes, may be NULL) / *tail: what the -d stream of the reference would show at each record, in the
+ * KGO_EV_* encoding: whether "after-hit" is printed (the record joined the list), whether the list was processed
+ * or cleared before / after that, whether that printed CALL + "after-call", and whether the list then kept its
+ * last two members (KGJ:406-409, 441-453, 470-473, 498-501). */
 static int gather_sorted(const kgo_params *p, const kgo_hit_rec *all, int64_t n, uint32_t container,
-                         kgo_otu_rec *oi, cvec *calls, hitlist *hits)
+                         kgo_otu_rec *oi, cvec *calls, hitlist *hits, uint8_t *trace, uint8_t *tail)
 {
     int crash = 0;
     hits->n = 0;
     int currentFI = 0;
+    if (tail) *tail = 0;
     for (int64_t k = 0; k < n && !crash; k++) {
         const kgo_hit_rec *ph = &all[k];
         int avgOffEnd = ph->avgOffFromEnd;
         int fI = ph->fI;
+        unsigned ev = 0;
         if (hits->n > 0 &&
             (int32_t)((uint32_t)hits->a[hits->n - 1].from0InProt + (uint32_t)p->max_gap) < ph->from0InProt) {   /* KGJ:477-484 */
-            if (hits->n >= p->min_hits)
+            ev |= KGO_EV_RESET_BEFORE;
+            if (hits->n >= p->min_hits) {
+                int64_t before = calls->n;
                 currentFI = process_set_of_hits(p, hits, currentFI, oi, container, calls, &crash);
-            else
+                if (calls->n > before) ev |= KGO_EV_CALL_BEFORE;
+                if (hits->n == 2) ev |= KGO_EV_KEEP2_BEFORE;
+            } else
                 hits->n = 0;
             if (crash) break;
         }
@@ -487,15 +497,24 @@ static int gather_sorted(const kgo_params *p, const kgo_hit_rec *all, int64_t n,
                     hits->a = na; hits->cap = nc;
                 }
                 hits->a[hits->n++] = *ph;
+                ev |= KGO_EV_ACCEPTED;
             }
             if (hits->n > 1 && currentFI != fI &&
                 hits->a[hits->n - 2].fI == hits->a[hits->n - 1].fI) {      /* KGJ:503-508 */
+                int64_t before = calls->n;
+                ev |= KGO_EV_RESET_AFTER;
                 currentFI = process_set_of_hits(p, hits, currentFI, oi, container, calls, &crash);
+                if (calls->n > before) ev |= KGO_EV_CALL_AFTER;
+                if (hits->n == 2) ev |= KGO_EV_KEEP2_AFTER;
             }
         }
+        if (trace) trace[k] = (uint8_t)ev;
     }
-    if (!crash && hits->n >= p->min_hits)                        /* KGJ:511-513 */
+    if (!crash && hits->n >= p->min_hits) {                      /* KGJ:511-513 */
+        int64_t before = calls->n;
         process_set_of_hits(p, hits, currentFI, oi, container, calls, &crash);
+        if (tail && calls->n > before) *tail = KGO_EV_TAIL_CALL;
+    }
     return crash ? -crash : 0;
 }
 
@@ -528,7 +547,7 @@ int64_t kgo_gather_hits(const kgo_params *p, kgo_hit_rec *hits, int64_t n, uint3
     free(t); free(tmp);
     cvec calls = {0};
     hitlist hl = {0};
-    int rc = gather_sorted(p, hits, n, container, otu, &calls, &hl);
+    int rc = gather_sorted(p, hits, n, container, otu, &calls, &hl, NULL, NULL);
     free(hl.a);
     int64_t nc = calls.n;
     for (int64_t i = 0; i < nc && i < cap; i++) calls_out[i] = calls.a[i];
@@ -542,7 +561,7 @@ void kgo_result_free(kgo_result *r)
 {
     if (!r) return;
     free(r->hits); free(r->container_hit_start); free(r->calls);
-    free(r->container_call_start); free(r->otu);
+    free(r->container_call_start); free(r->otu); free(r->hit_events); free(r->container_tail_events);
     memset(r, 0, sizeof *r);
 }
 
@@ -619,7 +638,10 @@ int kgo_run(const uint8_t *table, size_t table_nbytes, const kgo_params *p,
     out->container_hit_start = (int64_t *)calloc((size_t)n_cont + 1, sizeof(int64_t));
     out->container_call_start = (int64_t *)calloc((size_t)n_cont + 1, sizeof(int64_t));
     out->otu = (kgo_otu_rec *)calloc((size_t)(n_seqs > 0 ? n_seqs : 1), sizeof(kgo_otu_rec));
-    if (!out->container_hit_start || !out->container_call_start || !out->otu) {
+    out->hit_events = (uint8_t *)calloc((size_t)(hits.n > 0 ? hits.n : 1), 1);
+    out->container_tail_events = (uint8_t *)calloc((size_t)(n_cont > 0 ? n_cont : 1), 1);
+    if (!out->container_hit_start || !out->container_call_start || !out->otu || !out->hit_events ||
+        !out->container_tail_events) {
         free(hits.a); kgo_result_free(out); return fail("out of memory in grouping");
     }
     {
@@ -638,7 +660,8 @@ int kgo_run(const uint8_t *table, size_t table_nbytes, const kgo_params *p,
             int64_t c = sq * per + f;
             out->container_call_start[c] = calls.n;
             int64_t a = out->container_hit_start[c], b = out->container_hit_start[c + 1];
-            int g = gather_sorted(p, hits.a + a, b - a, (uint32_t)c, oi, &calls, &hl);
+            int g = gather_sorted(p, hits.a + a, b - a, (uint32_t)c, oi, &calls, &hl, out->hit_events + a,
+                                  out->container_tail_events + c);
             if (g) { rc = fail("reference crash path reached in processSetOfHits / out of memory"); break; }
         }
     }

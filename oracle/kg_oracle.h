@@ -65,7 +65,19 @@ typedef struct {
     /* phase timers, KGJ:794,803,819 (seconds) */
     double t_prepare, t_lookup, t_group;
     int32_t lookup_aborted;         /* literal mode: stream ran off the end (KGJ:799-802) in >=1 batch */
+    uint8_t *hit_events;            /* n_hits: KGO_EV_* of each record (the -d stream, see gather_sorted) */
+    uint8_t *container_tail_events; /* n_containers: KGO_EV_TAIL_CALL                               */
 } kgo_result;
+
+/* what the reference's -d stream shows at one hit record, in the order it happens */
+#define KGO_EV_ACCEPTED      0x01u  /* "after-hit" printed: the record joined the hits list (KGJ:496-501)     */
+#define KGO_EV_RESET_BEFORE  0x02u  /* gap rule fired before it (KGJ:477-484)                                 */
+#define KGO_EV_CALL_BEFORE   0x04u  /*   and printed CALL + "after-call" (KGJ:397-409)                        */
+#define KGO_EV_KEEP2_BEFORE  0x08u  /*   and the list kept its last two members (KGJ:441-449)                 */
+#define KGO_EV_RESET_AFTER   0x10u  /* pair rule fired after it (KGJ:503-508)                                 */
+#define KGO_EV_CALL_AFTER    0x20u
+#define KGO_EV_KEEP2_AFTER   0x40u
+#define KGO_EV_TAIL_CALL     0x01u  /* per container: the final flush printed a CALL (KGJ:511-513)            */
 
 /* ---- single functions (KAT surface) ---- */
 int     kgo_to_amino_acid_off(int c);                         /* KGJ:111-175 */

@@ -32,7 +32,7 @@ class Result(C.Structure):
                 ("container_call_start", C.c_void_p), ("otu", C.c_void_p),
                 ("residues", C.c_int64), ("windows_valid", C.c_int64), ("slots_inspected", C.c_int64),
                 ("t_prepare", C.c_double), ("t_lookup", C.c_double), ("t_group", C.c_double),
-                ("lookup_aborted", C.c_int32)]
+                ("lookup_aborted", C.c_int32), ("hit_events", C.c_void_p), ("container_tail_events", C.c_void_p)]
 
 
 _lib = None
@@ -99,6 +99,8 @@ def run(table_image, seq, offsets, aa=False, order_constraint=False, min_hits=5,
         "calls": _view(r.calls, r.n_calls, CALL_DTYPE),
         "container_call_start": _view(r.container_call_start, r.n_containers + 1, np.dtype("<i8")),
         "otu": _view(r.otu, r.n_seqs, OTU_DTYPE),
+        "hit_events": _view(r.hit_events, r.n_hits, np.dtype("u1")),
+        "container_tail_events": _view(r.container_tail_events, r.n_containers, np.dtype("u1")),
         "residues": r.residues, "windows_valid": r.windows_valid, "slots_inspected": r.slots_inspected,
         "t_prepare": r.t_prepare, "t_lookup": r.t_lookup, "t_group": r.t_group,
         "lookup_aborted": bool(r.lookup_aborted),

@@ -16,6 +16,9 @@ def assert_same_records(gpu, ora, what=""):
     assert np.array_equal(gpu.container_call_start(), ora["container_call_start"]), what + " container_call_start"
     go, oo = gpu.otu(), ora["otu"]
     assert go.tobytes() == oo.tobytes(), "%s OTU records differ (first diff at %s)" % (what, _first_diff(go, oo))
+    ge, oe = gpu.hit_events(), ora["hit_events"]              # what the -d stream shows at every record
+    assert np.array_equal(ge, oe), "%s hit events differ at %s" % (what, np.flatnonzero(ge != oe)[:5])
+    assert np.array_equal(gpu.container_tail_events(), ora["container_tail_events"]), what + " tail events"
     assert gpu.stats["residues"] == ora["residues"], what + " residues"
     import os
     mode = os.environ.get("KG_PARTITION")

@@ -1,0 +1,112 @@
+"""The -d debug stream (KGJ:376-383 displayHits, 406-409 after-call, 470-473 HIT, 498-501 after-hit).
+
+The aggregation kernel leaves one event byte per hit record (include/kmerguts_hip.h KG_EV_*); the host front
+ends only print from them.  Checked here:
+  * CPU: the C oracle's event bytes, rendered by the host mirror's printer, give the text the literal
+    pure-Python model of the reference prints with debug = true;
+  * GPU: both front ends (KmerGutsJava.main and the native kmer_guts) with -d print that same text.
+(The event bytes of the HIP path are compared with the oracle's in every parity test, tests/helpers.py.)
+"""
+import io
+import os
+
+import numpy as np
+import pytest
+
+INFO = ("Temp. directory: ", "Preparation time: ", "Kmer-table info: ", "Lookup time: ", "Grouping time: ")
+
+CASES = [  # (dna, order_constraint, min_hits, max_gap, min_weighted_hits)
+    (True, False, 3, 200, 0),
+    (True, True, 2, 200, 0),
+    (True, False, 2, 12, 3),
+    (False, False, 3, 200, 0),
+    (False, True, 2, 30, 0),
+    (False, False, 5, 8, 0),
+]
+
+
+def _case(dna, seed):
+    from kmergutsjava_amd import synth
+    seq, off, rec, keys = synth.high_density_config(4, 60, 1009, 400, seed=seed, dna=dna)
+    img = synth.table_image(rec)
+    sb = seq.numpy().tobytes()
+    off = np.asarray(off, dtype=np.int64)
+    fa = "".join(">s%d some text\n%s\n" % (k, sb[off[k]:off[k + 1]].decode()) for k in range(len(off) - 1))
+    fn = ["synthetic function %d" % i for i in range(64)]
+    return img, sb, off, fa, fn
+
+
+def _model_text(img, fn, fa, dna, oc, mh, gap, mw):
+    from oracle import kgj_model as M
+    return M.Model(aa=not dna, order_constraint=oc, min_hits=mh, min_weighted_hits=mw, max_gap=gap, debug=True).run(img, fn, fa)
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_oracle_events_print_the_models_debug_text(oracle, case):
+    from kmergutsjava_amd import KmerGutsJava
+    dna, oc, mh, gap, mw = CASES[case]
+    img, sb, off, fa, fn = _case(dna, 700 + case)
+    want = _model_text(img, fn, fa, dna, oc, mh, gap, mw)
+    assert "after-hit: hits: " in want and "after-call: hits: " in want and "HIT\t" in want
+    o = oracle.run(img, sb, off, aa=not dna, order_constraint=oc, min_hits=mh, min_weighted_hits=mw, max_gap=gap)
+    k = KmerGutsJava()
+    k.aa, k.debug = not dna, True
+    per = 1 if k.aa else 6
+    chs, ccs = o["container_hit_start"], o["container_call_start"]
+    pw = io.StringIO()
+    for s in range(len(off) - 1):
+        cs = range(s * per, s * per + per)
+        dbg = [(o["hits"][chs[c]:chs[c + 1]], o["hit_events"][chs[c]:chs[c + 1]], int(o["container_tail_events"][c])) for c in cs]
+        k.write_record(pw, "s%d" % s, int(off[s + 1] - off[s]), [o["calls"][ccs[c]:ccs[c + 1]] for c in cs], o["otu"][s],
+                       fn, dbg)
+    assert pw.getvalue() == want
+    ev = o["hit_events"]
+    assert (ev & 0x02).any() or (ev & 0x10).any()
+
+
+def test_events_keep_two_and_order_constraint_rejections(oracle):
+    """The pair rule's carry (KGJ:441-449) and -O rejections (KGJ:490-494) are visible in the event bytes."""
+    img, sb, off, fa, fn = _case(True, 731)
+    o = oracle.run(img, sb, off, order_constraint=True, min_hits=2)
+    ev = o["hit_events"]
+    assert (ev & 0x01 == 0).any(), "no record was rejected by the order constraint"
+    o = oracle.run(img, sb, off, min_hits=2)
+    ev = o["hit_events"]
+    assert (ev & 0x40).any(), "no pair-rule carry in the fixture"
+    assert (ev & 0x01).all()
+    # a reset that prints a CALL is always a reset
+    assert not ((ev & 0x04 != 0) & (ev & 0x02 == 0)).any() and not ((ev & 0x20 != 0) & (ev & 0x10 == 0)).any()
+    n_calls = int(((ev & 0x04) != 0).sum() + ((ev & 0x20) != 0).sum() + (o["container_tail_events"] & 1).sum())
+    assert n_calls == len(o["calls"])
+
+
+def _strip_info(text):
+    keep, info = [], []
+    for ln in text.splitlines(True):
+        (info if ln.startswith(INFO) else keep).append(ln)
+    return "".join(keep), info
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_front_ends_print_the_debug_stream(case, tmp_path):
+    import subprocess
+    from kmergutsjava_amd import synth, build, KmerGutsJava
+    dna, oc, mh, gap, mw = CASES[case]
+    img, sb, off, fa, fn = _case(dna, 700 + case)
+    want = _model_text(img, fn, fa, dna, oc, mh, gap, mw)
+    synth.write_data_dir(str(tmp_path / "d"), img, 64, gz=False)
+    (tmp_path / "q.fa").write_text(fa)
+    args = ["-D", str(tmp_path / "d"), "-q", str(tmp_path / "q.fa"), "-d", "-m", str(mh), "-g", str(gap), "-M", str(mw)]
+    if not dna:
+        args.append("-a")
+    if oc:
+        args.append("-O")
+    KmerGutsJava.main(args + ["-o", str(tmp_path / "py.txt")])
+    subprocess.run([build.build_cli()] + args + ["-o", str(tmp_path / "cli.txt")], check=True, stdout=subprocess.DEVNULL)
+    for name in ("py.txt", "cli.txt"):
+        got, info = _strip_info((tmp_path / name).read_text())
+        assert got == want, name
+        assert [ln.split(":")[0] for ln in info] == ["Temp. directory", "Preparation time", "Kmer-table info", "Lookup time",
+                                                     "Grouping time"], name
+        assert "Kmer-table info: numSigs=1009, entrySize=24, version=1\n" in info, name
