@@ -57,6 +57,7 @@ struct TableView {
     uint64_t limit;      // complete records present; the reference's stream ends here (EOF == not found)
     uint64_t num_sigs;   // modulus of the home slot (KGJ:969)
     uint64_t magic;      // floor(2^64 / num_sigs)
+    uint32_t m35;        // floor(2^35 / num_sigs) when 64 <= num_sigs < 2^31 (split_fast applies), else 0
 };
 
 // ---------------------------------------------------------------------------------------
@@ -69,21 +70,63 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ uint32_t tag_of(uint64_t k)
-{
-    uint32_t h = (uint32_t)k * 0x9E3779B1u ^ (uint32_t)(k >> 32) * 0x85EBCA6Bu;
-    h ^= h >> 15;
-    uint32_t t = h >> 24;
-    return t == kTagEmpty ? 0xFEu : t;
-}
-
-// exact v % num_sigs for v < 2^63 (one correction step suffices: q_est in {q-1, q})
-__device__ __forceinline__ uint64_t home_slot(uint64_t v, const TableView &t)
+// A query k-mer is handled as (q, home slot) with value = q * num_sigs + slot (KGJ:969: slot = value % numSigs).
+//
+// split_value: exact quotient / remainder of any v < 2^63 (one correction step suffices: q_est in {q-1, q}).
+__device__ __forceinline__ uint64_t split_value(uint64_t v, const TableView &t, uint64_t *q_out)
 {
     uint64_t q = __umul64hi(v, t.magic);
     uint64_t r = v - q * t.num_sigs;
-    if (r >= t.num_sigs) r -= t.num_sigs;
+    if (r >= t.num_sigs) { r -= t.num_sigs; q += 1; }
+    *q_out = q;
     return r;
+}
+
+// split_fast: the same for value = hi * 160000 + lo (hi, lo < 160000: the two 4-residue half codes) when
+// 64 <= n < 2^31, with 24-bit multiplies (full rate) and two 32-bit ones instead of 64-bit arithmetic.
+//   vh = value >> 3 exactly (hi * 160000 is a multiple of 8), < 2^32;  m35 = floor(2^35 / n)
+//   q_est = floor(vh * m35 / 2^32) <= value / n, and value / n - vh * m35 / 2^32 < value / 2^35 + 8 / n < 0.75 + 0.125,
+//   so q_est is floor(value / n) or one less, the remainder estimate is < 2n < 2^32 and 32-bit arithmetic is exact.
+__device__ __forceinline__ uint32_t split_fast(uint32_t hi, uint32_t lo, uint32_t n, uint32_t m35, uint32_t *q_out)
+{
+    const uint32_t vh = __umul24(hi, 20000u) + (lo >> 3);
+    const uint32_t v32 = __umul24(hi, 160000u) + lo;        // value mod 2^32
+    uint32_t q = __umulhi(vh, m35);
+    uint32_t r = v32 - q * n;
+    if (r >= n) { r -= n; q += 1; }
+    *q_out = q;
+    return r;
+}
+
+// the two half codes of a k-mer -> (q, slot); uniform choice of the arithmetic
+__device__ __forceinline__ uint64_t split_halves(uint32_t hi, uint32_t lo, const TableView &t, uint64_t *q_out)
+{
+    if (t.m35) {
+        uint32_t q;
+        const uint32_t r = split_fast(hi, lo, (uint32_t)t.num_sigs, t.m35, &q);
+        *q_out = q;
+        return r;
+    }
+    return split_value((uint64_t)hi * 160000ull + lo, t, q_out);
+}
+
+// 8-bit fingerprint of a k-mer, from its (q, slot) form: 24-bit multiplies only; the byte is taken from the
+// middle of the products, where every low input bit has spread.  Keys that share a home slot differ in q and
+// never collide; neighbours collide at the ideal 1/255 (tools/notes in profiles/r01_partition_path.md).
+__device__ __forceinline__ uint32_t tag_qs(uint64_t q, uint64_t slot)
+{
+    const uint32_t q32 = (uint32_t)q ^ (uint32_t)(q >> 32);
+    const uint32_t h = __umul24((uint32_t)slot, 0x9E3779u) ^ __umul24((uint32_t)(slot >> 24), 0x85EBCBu) ^
+                       __umul24(q32 ^ (q32 >> 19), 0xC2B2AFu);
+    const uint32_t t = (h >> 16) & 0xFFu;
+    return t == kTagEmpty ? 0xFEu : t;
+}
+
+// home slot only
+__device__ __forceinline__ uint64_t home_slot(uint64_t v, const TableView &t)
+{
+    uint64_t q;
+    return split_value(v, t, &q);
 }
 
 // 0x80 in every byte of x that is zero, nothing else (no cross-byte carries)
@@ -166,6 +209,14 @@ constexpr uint32_t aa_code_of(char c)
         if (alpha[i] == c) return i;
     return 20;
 }
+__device__ __forceinline__ uint32_t aa_code_of_rt(char c)
+{
+    uint32_t r = 20;
+#pragma unroll
+    for (uint32_t i = 0; i < 20; i++)
+        if ("ACDEFGHIKLMNPQRSTVWY"[i] == c) r = i;
+    return r;
+}
 constexpr uint32_t codon16(int i)
 {
     return aa_code_of(kGeneticCode[i * 4]) | (aa_code_of(kGeneticCode[i * 4 + 1]) << 5) |
@@ -182,36 +233,71 @@ __device__ __forceinline__ uint32_t dna_code(uint32_t c)
     return u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : (u == 'T' || u == 'U') ? 3u : 4u;
 }
 
+// The encode stage is table driven and branch free.  Residue codes travel as dwords with "not an amino acid"
+// (KGJ:111-175 code 20; stop codons, codons with a non-ACGTU base) = kBadCode = 2^20.  A 4-residue half code is
+//     c0 * 8000 + c1 * 400 + c2 * 20 + c3   (mod 2^32),
+// < 160000 < 2^20 when all four are valid; with bad residues it is (k mod 4096) * 2^20 + (something < 160000),
+// k a non-empty subset sum of {8000, 400, 20, 1}: none of the 15 sums is a multiple of 4096, so a half code is
+// valid iff it is < 2^20 and no per-residue compare is needed (encodedKmer's early return, KGJ:283-285).
+constexpr uint32_t kBadCode = 1u << 20;
+__device__ __forceinline__ bool half_ok(uint32_t a, uint32_t b) { return ((a | b) >> 20) == 0u; }
+__device__ __forceinline__ uint32_t half_code(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
+{
+    return __umul24(c0, 8000u) + __umul24(c1, 400u) + __umul24(c2, 20u) + c3;
+}
+
+// Lookup tables shared by the waves of a workgroup (built once per workgroup by encode_init).
+struct EncTablesDna {
+    uint32_t fwd[128];    // [b0*25 + b1*5 + b2] (base codes 0..4): code of codon b0 b1 b2 (translate, KGJ:320-343)
+    uint32_t rev[128];    // same index: code of the reverse-complement codon compl(b2) compl(b1) compl(b0) (KGJ:263-272)
+    uint8_t base[256];    // dnaChar
+};
+struct EncTablesAa {
+    uint32_t code[256];   // toAminoAcidOff (KGJ:111-175): 0..19, else kBadCode
+};
+
 struct __attribute__((aligned(16))) WaveLdsDna {
     uint32_t H[208];      // '+' half codes: 4 codons starting at base q   (q < 204)
     uint32_t G[208];      // '-' half codes: 4 reverse-complement codons over bases q..q+11
-    uint32_t t16[16];
+    uint32_t F[216];      // code of the forward codon starting at base q   (q < 213)
+    uint32_t R[216];      // code of the reverse-complement codon over bases q..q+2
     uint8_t bc[232];      // base codes of the block's 215 bases
-    uint8_t F[224];       // aa code of forward codon starting at base q   (q < 213)
-    uint8_t R[224];       // aa code of reverse-complement codon over bases q..q+2
 };
 
 struct __attribute__((aligned(16))) WaveLdsAa {
     uint32_t H4[80];      // half codes of 4 residues starting at q (q < 68)
-    uint8_t code[80];
-    uint8_t lut[256];
+    uint32_t code[80];
 };
 
 template <bool AA> struct WaveLds;
-template <> struct WaveLds<false> { typedef WaveLdsDna type; };
-template <> struct WaveLds<true> { typedef WaveLdsAa type; };
+template <> struct WaveLds<false> { typedef WaveLdsDna type; typedef EncTablesDna tables; };
+template <> struct WaveLds<true> { typedef WaveLdsAa type; typedef EncTablesAa tables; };
 
-// once per wave: the lookup tables that live in the wave's LDS region
+// once per workgroup (all threads call; the caller synchronises the workgroup afterwards)
 template <bool AA>
-__device__ __forceinline__ void encode_init(typename WaveLds<AA>::type &l, int lane)
+__device__ __forceinline__ void encode_init(typename WaveLds<AA>::tables &t, uint32_t tid, uint32_t n_threads)
 {
     if constexpr (AA) {
-        // toAminoAcidOff (KGJ:111-175) as a 256-entry table: uppercase letters only
-        for (int b = lane; b < 256; b += 64) l.lut[b] = (uint8_t)aa_code_of((char)b);
+        for (uint32_t b = tid; b < 256; b += n_threads) {
+            const uint32_t c = aa_code_of_rt((char)b);
+            t.code[b] = c < 20 ? c : kBadCode;
+        }
     } else {
-        if (lane < 16) l.t16[lane] = kCodon16[lane];
+        for (uint32_t b = tid; b < 256; b += n_threads) t.base[b] = (uint8_t)dna_code(b);
+        for (uint32_t i = tid; i < 128; i += n_threads) {
+            const uint32_t b0 = i / 25u, b1 = (i / 5u) % 5u, b2 = i % 5u;
+            uint32_t f = kBadCode, r = kBadCode;
+            if (i < 125 && b0 < 4 && b1 < 4 && b2 < 4) {
+                // codon index c1*16+c2*4+c3 (KGJ:331-337); kCodon16[c1*4+c2] packs the four c3 codes
+                f = (kCodon16[b0 * 4 + b1] >> (b2 * 5)) & 31u;
+                r = (kCodon16[(3 - b2) * 4 + (3 - b1)] >> ((3 - b0) * 5)) & 31u;   // compl code = 3 - code
+                if (f >= 20) f = kBadCode;                                         // stop codon '*' -> code 20
+                if (r >= 20) r = kBadCode;
+            }
+            t.fwd[i] = f;
+            t.rev[i] = r;
+        }
     }
-    wave_sync();
 }
 
 // The raw characters of one block, 4 per lane (lane q holds characters q, q+64, q+128, q+192 of the block's
@@ -243,82 +329,72 @@ __device__ __forceinline__ void load_block_chars(const uint8_t *__restrict__ seq
 
 // Leave the 4-residue half codes of one block in LDS (all lanes of the wave), from its raw characters.
 template <bool AA>
-__device__ __forceinline__ void encode_chars(typename WaveLds<AA>::type &l, const uint32_t (&raw)[4], int lane)
+__device__ __forceinline__ void encode_chars(typename WaveLds<AA>::type &l, const typename WaveLds<AA>::tables &t,
+                                             const uint32_t (&raw)[4], int lane)
 {
     if constexpr (AA) {
         // ---- protein: windows i = 64j + lane
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const uint32_t q = (uint32_t)lane + 64u * k;
-            if (q < 72) l.code[q] = l.lut[raw[k] & 255u];
+            if (q < 72) l.code[q] = t.code[raw[k] & 255u];
         }
         wave_sync();
-        for (uint32_t q = lane; q < 68; q += 64) {
-            uint32_t c0 = l.code[q], c1 = l.code[q + 1], c2 = l.code[q + 2], c3 = l.code[q + 3];
-            bool ok = (c0 < 20) & (c1 < 20) & (c2 < 20) & (c3 < 20);
-            l.H4[q] = ok ? c0 * 8000u + c1 * 400u + c2 * 20u + c3 : kInvalid;
-        }
+        for (uint32_t q = lane; q < 68; q += 64) l.H4[q] = half_code(l.code[q], l.code[q + 1], l.code[q + 2], l.code[q + 3]);
         wave_sync();
     } else {
         // ---- DNA: 215 bases -> base codes, codon codes for both strands, then 4-codon half codes
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t q = (uint32_t)lane + 64u * k;
-            if (q < 232) l.bc[q] = (uint8_t)dna_code(raw[k]);
+            if (q < 232) l.bc[q] = t.base[raw[k] & 255u];
         }
         wave_sync();
         for (uint32_t q = lane; q < 213; q += 64) {
-            uint32_t b0 = l.bc[q], b1 = l.bc[q + 1], b2 = l.bc[q + 2];
-            bool ok = (b0 < 4) & (b1 < 4) & (b2 < 4);
-            // translate (KGJ:320-343): codon index c1*16+c2*4+c3; non-ACGTU -> 'x' -> code 20
-            uint32_t f = (l.t16[(b0 * 4 + b1) & 15] >> ((b2 & 3) * 5)) & 31u;
-            // reverse strand (KGJ:263-272 + 320-343): codon = compl(b2) compl(b1) compl(b0); compl code = 3 - code
-            uint32_t r = (l.t16[((3 - b2) * 4 + (3 - b1)) & 15] >> (((3 - b0) & 3) * 5)) & 31u;
-            l.F[q] = (uint8_t)(ok ? f : 20u);
-            l.R[q] = (uint8_t)(ok ? r : 20u);
+            const uint32_t i = __umul24(__umul24(l.bc[q], 5u) + l.bc[q + 1], 5u) + l.bc[q + 2];
+            l.F[q] = t.fwd[i];
+            l.R[q] = t.rev[i];
         }
         wave_sync();
         for (uint32_t q = lane; q < 204; q += 64) {
-            uint32_t f0 = l.F[q], f1 = l.F[q + 3], f2 = l.F[q + 6], f3 = l.F[q + 9];
-            uint32_t r0 = l.R[q], r1 = l.R[q + 3], r2 = l.R[q + 6], r3 = l.R[q + 9];
-            bool okf = (f0 < 20) & (f1 < 20) & (f2 < 20) & (f3 < 20);
-            bool okr = (r0 < 20) & (r1 < 20) & (r2 < 20) & (r3 < 20);
-            l.H[q] = okf ? f0 * 8000u + f1 * 400u + f2 * 20u + f3 : kInvalid;
+            l.H[q] = half_code(l.F[q], l.F[q + 3], l.F[q + 6], l.F[q + 9]);
             // on the '-' strand the codon over the highest bases comes first
-            l.G[q] = okr ? r3 * 8000u + r2 * 400u + r1 * 20u + r0 : kInvalid;
+            l.G[q] = half_code(l.R[q + 9], l.R[q + 6], l.R[q + 3], l.R[q]);
         }
         wave_sync();
     }
 }
 
 template <bool AA>
-__device__ __forceinline__ void encode_block(typename WaveLds<AA>::type &l, const uint8_t *__restrict__ seq,
-                                             const BlockDesc &bd, int lane)
+__device__ __forceinline__ void encode_block(typename WaveLds<AA>::type &l, const typename WaveLds<AA>::tables &t,
+                                             const uint8_t *__restrict__ seq, const BlockDesc &bd, int lane)
 {
     uint32_t raw[4];
     load_block_chars<AA>(seq, bd, lane, raw);
-    encode_chars<AA>(l, raw, lane);
+    encode_chars<AA>(l, t, raw, lane);
 }
 
-// encodedKmer (KGJ:274-292) of the lane's window in row r (wave-uniform; DNA: strand r/3, phase r%3).
+// encodedKmer (KGJ:274-292) of the lane's window in row r (wave-uniform; DNA: strand r/3, phase r%3), as its
+// two half codes: value = hi * 160000 + lo.
 template <bool AA>
-__device__ __forceinline__ bool row_value(const typename WaveLds<AA>::type &l, int r, int lane, const BlockDesc &bd,
-                                          uint64_t *val)
+__device__ __forceinline__ bool row_halves(const typename WaveLds<AA>::type &l, int r, int lane, const BlockDesc &bd,
+                                           uint32_t *hi_out, uint32_t *lo_out)
 {
     if constexpr (AA) {
         uint32_t hi = l.H4[lane], lo = l.H4[lane + 4];
         uint32_t i = bd.j * kAaWinPerBlock + lane;
-        *val = (uint64_t)hi * 160000ull + lo;
+        *hi_out = hi; *lo_out = lo;
         // queried iff i < len - 8 (KGJ:912: i < pIseq.length - K -- the last window is never queried)
-        return (hi != kInvalid) & (lo != kInvalid) & ((uint64_t)i + 8 < (uint64_t)bd.len);
+        return half_ok(hi, lo) & ((uint64_t)i + 8 < (uint64_t)bd.len);
     } else {
         const bool minus = r >= 3;
         const uint32_t pl = 3u * lane + (uint32_t)(minus ? r - 3 : r);
         const uint32_t *hc = minus ? l.G : l.H;
         uint32_t a = hc[pl], b = hc[pl + 12];
         // '+': first four codons are the high half; '-': the codons over the higher bases are
-        *val = minus ? (uint64_t)b * 160000ull + a : (uint64_t)a * 160000ull + b;
-        return (a != kInvalid) & (b != kInvalid);
+        *hi_out = minus ? b : a;
+        *lo_out = minus ? a : b;
+        return half_ok(a, b);
     }
 }
 
@@ -358,19 +434,19 @@ __device__ __forceinline__ void row_record_key(const BlockDesc &bd, int r, int l
 // k-mer, an empty slot or the end of the stream; never wrap).  16 tags per load, records touched only on a
 // fingerprint match; the rare longer walks share one copy of the generic walk, rows picked by register muxes.
 // On return bit q of the result is set iff query q was found, with ent[q] = the record's payload.
-template <int N, bool COUNTERS, bool HAVE_SLOT = false>
-__device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t (&val)[N], bool (&valid)[N],
-                                            Payload (&ent)[N], unsigned long long &ctr_valid,
-                                            unsigned long long &ctr_slots, const uint64_t *known_slot = nullptr)
+// val[q] = the k-mer value (compared with the record keys), home_in[q] / fp[q] = its home slot and fingerprint.
+template <int N, bool COUNTERS>
+__device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t (&val)[N], const uint64_t (&home_in)[N],
+                                            const uint32_t (&fp)[N], bool (&valid)[N], Payload (&ent)[N],
+                                            unsigned long long &ctr_valid, unsigned long long &ctr_slots)
 {
     uint64_t cand[N];     // slot under examination
-    uint32_t fp[N], skip[N];
+    uint32_t skip[N];
     Tags16 tg[N];
     uint64_t home[COUNTERS ? N : 1];
 #pragma unroll
     for (int q = 0; q < N; q++) {
-        cand[q] = HAVE_SLOT ? known_slot[q] : home_slot(val[q], tab);
-        fp[q] = tag_of(val[q]);
+        cand[q] = home_in[q];
         if (COUNTERS) { home[q] = cand[q]; if (valid[q]) ctr_valid++; }   // query k-mers (KGJ:913-920)
         valid[q] = valid[q] && cand[q] < tab.limit;     // beyond the stream: EOF, not found, nothing inspected
         cand[q] = probe_window(cand[q], &skip[q]);
@@ -488,7 +564,8 @@ __device__ __forceinline__ void flush_counters(unsigned long long ctr_valid, uns
 template <bool AA, bool COUNTERS, int RPG>
 __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
     const uint8_t *__restrict__ entries, const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, uint64_t magic,
-    const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t n_blocks, uint32_t *__restrict__ counts,
+    uint32_t m35, const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t n_blocks,
+    uint32_t *__restrict__ counts,
     uint32_t *__restrict__ block_stage_base, kg_hit *__restrict__ stage, unsigned long long *cursor, uint64_t stage_cap,
     uint32_t stage_chunk, unsigned long long *ctr)
 {
@@ -496,15 +573,17 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
     constexpr int NG = ROWS / RPG;
     static_assert(ROWS % RPG == 0, "RPG must divide the row count");
     __shared__ typename WaveLds<AA>::type lds[kWavesPerWG];
+    __shared__ typename WaveLds<AA>::tables enc_tables;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerWG + wave);
     const uint32_t n_waves = gridDim.x * kWavesPerWG;
     TableView tab;
-    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic;
+    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic; tab.m35 = m35;
 
     typename WaveLds<AA>::type &l = lds[wave];
-    encode_init<AA>(l, lane);
+    encode_init<AA>(enc_tables, threadIdx.x, blockDim.x);
+    __syncthreads();
 
     unsigned long long ctr_valid = 0, ctr_slots = 0;
     unsigned long long res_at = 0, res_end = 0;          // this wave's staging reservation (uniform)
@@ -512,16 +591,24 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
     for (uint32_t it_v = wave_global; it_v < n_blocks; it_v += n_waves) {
         const uint32_t it = __builtin_amdgcn_readfirstlane(it_v);
         const BlockDesc bd = blocks[it];
-        encode_block<AA>(l, seq, bd, lane);
+        encode_block<AA>(l, enc_tables, seq, bd, lane);
 
         for (int g = 0; g < NG; g++) {
-            uint64_t val[RPG];
+            uint64_t val[RPG], home[RPG];
+            uint32_t fp[RPG];
             bool valid[RPG];
 #pragma unroll
-            for (int q = 0; q < RPG; q++) valid[q] = row_value<AA>(l, g * RPG + q, lane, bd, &val[q]);
+            for (int q = 0; q < RPG; q++) {
+                uint32_t hi, lo;
+                uint64_t quo;
+                valid[q] = row_halves<AA>(l, g * RPG + q, lane, bd, &hi, &lo);
+                home[q] = split_halves(hi, lo, tab, &quo);
+                fp[q] = tag_qs(quo, home[q]);
+                val[q] = (uint64_t)hi * 160000ull + lo;
+            }
 
             Payload ent[RPG];
-            const uint32_t foundm = probe_n<RPG, COUNTERS>(tab, val, valid, ent, ctr_valid, ctr_slots);
+            const uint32_t foundm = probe_n<RPG, COUNTERS>(tab, val, home, fp, valid, ent, ctr_valid, ctr_slots);
 
             // ---- ordered compaction: ballot per row, staging records handed out from the wave's reservation
             uint32_t cnt[RPG], rank[RPG];
@@ -731,9 +818,11 @@ __global__ void container_starts_kernel(const uint32_t *ibase, uint32_t n_seqs, 
 
 // ---------------------------------------------------------------------------------------
 // tag array from the 24-byte records (one pass over the table at load time)
-__global__ void build_tags_kernel(const uint8_t *entries, uint64_t limit, uint64_t n_tags, uint8_t *tags,
-                                  unsigned long long *occupied)
+__global__ void build_tags_kernel(const uint8_t *entries, uint64_t limit, uint64_t n_tags, uint64_t num_sigs, uint64_t magic,
+                                  uint8_t *tags, unsigned long long *occupied)
 {
+    TableView tab;
+    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic; tab.m35 = 0;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long occ = 0;
@@ -744,7 +833,9 @@ __global__ void build_tags_kernel(const uint8_t *entries, uint64_t limit, uint64
             uint2 a = p[0];
             int64_t key = (int64_t)(((uint64_t)a.y << 32) | a.x);
             if (key <= KG_MAX_ENCODED) {        // occupied (KGJ:1000); negative keys are occupied and never match
-                t = tag_of((uint64_t)key);
+                uint64_t q;                     // same (q, slot) form as the queries; garbage keys get some tag
+                const uint64_t slot = split_value((uint64_t)key, tab, &q);
+                t = tag_qs(q, slot);
                 occ++;
             }
         }

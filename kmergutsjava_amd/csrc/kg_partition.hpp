@@ -35,16 +35,6 @@ constexpr int kMaxBuckets = 1024;
 constexpr int kProbeN = 4;                  // queries per lane per iteration of the bucket probe
 constexpr uint32_t kUChunk = 512;           // records per reservation of the unordered hit list
 
-// exact quotient and remainder of v by num_sigs (see home_slot)
-__device__ __forceinline__ uint64_t home_slot_q(uint64_t v, uint64_t num_sigs, uint64_t magic, uint32_t *q_out)
-{
-    uint64_t q = __umul64hi(v, magic);
-    uint64_t r = v - q * num_sigs;
-    if (r >= num_sigs) { r -= num_sigs; q += 1; }
-    *q_out = (uint32_t)q;
-    return r;
-}
-
 constexpr uint64_t kEntInvalid = ~0ull;     // filler entry (padding of a 16-entry group)
 constexpr int kScatterWaves = 16;           // waves per scatter workgroup (one workgroup per CU: its LDS holds the buffers)
 constexpr uint32_t kGroup = 16;             // entries per write-combining buffer = one 128-byte line
@@ -53,7 +43,8 @@ template <bool AA>
 inline size_t scatter_lds_bytes(uint32_t n_buckets)
 {
     size_t enc = (sizeof(typename WaveLds<AA>::type) + 15) & ~(size_t)15;
-    return enc * kScatterWaves + (size_t)n_buckets * (kGroup * 8 + 8);
+    size_t tab = (sizeof(typename WaveLds<AA>::tables) + 15) & ~(size_t)15;
+    return enc * kScatterWaves + tab + (size_t)n_buckets * (kGroup * 8 + 8);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -65,8 +56,8 @@ inline size_t scatter_lds_bytes(uint32_t n_buckets)
 template <bool AA>
 __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t block_lo, uint32_t n_blocks /* of this launch */,
-    uint64_t limit, uint64_t num_sigs, uint64_t magic, uint32_t shift, uint32_t n_buckets, uint32_t cap, uint64_t *__restrict__ ent,
-    uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap, uint32_t *__restrict__ ovf_bucket,
+    uint64_t limit, uint32_t num_sigs /* 64 <= num_sigs < 2^31 */, uint32_t m35, uint32_t shift, uint32_t n_buckets, uint32_t cap,
+    uint64_t *__restrict__ ent, uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap, uint32_t *__restrict__ ovf_bucket,
     uint64_t *__restrict__ ovf_ent, unsigned long long *ctr)
 {
     constexpr int ROWS = AA ? 1 : 6;
@@ -75,12 +66,16 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char part_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Enc &l = *reinterpret_cast<Enc *>(part_lds + enc_bytes * wave);
-    uint64_t *buf = reinterpret_cast<uint64_t *>(part_lds + enc_bytes * kScatterWaves);
+    typedef typename WaveLds<AA>::tables Tables;
+    constexpr size_t tab_bytes = (sizeof(Tables) + 15) & ~(size_t)15;
+    Tables &enc_tables = *reinterpret_cast<Tables *>(part_lds + enc_bytes * kScatterWaves);
+    uint64_t *buf = reinterpret_cast<uint64_t *>(part_lds + enc_bytes * kScatterWaves + tab_bytes);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(buf + (size_t)n_buckets * kGroup);
     uint32_t *wrel = cnt + n_buckets;                 // entries already written to this workgroup's region of bucket b
     const uint32_t w = blockIdx.x, n_wg = gridDim.x;
+    const uint32_t limit32 = limit < 0xFFFFFFFFull ? (uint32_t)limit : 0xFFFFFFFFu;      // slots are < num_sigs < 2^31
     for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) { cnt[b] = 0; wrel[b] = 0; }
-    encode_init<AA>(l, lane);
+    encode_init<AA>(enc_tables, threadIdx.x, blockDim.x);
     __syncthreads();
 
     // Flush: wave v owns the buckets [v * per_wave, (v + 1) * per_wave); one lane looks at one bucket; the wave then
@@ -153,17 +148,16 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
             uint32_t raw[4] = {raw_next[0], raw_next[1], raw_next[2], raw_next[3]};
             const uint32_t itn = it + n_wg * kScatterWaves;
             if (itn < n_blocks) { bd_next = blocks[block_lo + itn]; load_block_chars<AA>(seq, bd_next, lane, raw_next); }
-            encode_chars<AA>(l, raw, lane);
+            encode_chars<AA>(l, enc_tables, raw, lane);
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
-                uint64_t v;
-                bool valid = row_value<AA>(l, r, lane, bd, &v);
-                uint32_t q;
-                const uint64_t slot = home_slot_q(v, num_sigs, magic, &q);
+                uint32_t hi, lo, q;
+                bool valid = row_halves<AA>(l, r, lane, bd, &hi, &lo);
+                const uint32_t slot = split_fast(hi, lo, num_sigs, m35, &q);
                 if (valid) n_valid++;                                   // query k-mers (KGJ:913-920)
-                valid = valid && slot < limit;                          // beyond the stream: never probed
-                bk[r] = (uint32_t)(slot >> shift);
-                const uint32_t low = (q << shift) | ((uint32_t)slot & ((1u << shift) - 1u));
+                valid = valid && slot < limit32;                        // beyond the stream: never probed
+                bk[r] = slot >> shift;
+                const uint32_t low = (q << shift) | (slot & ((1u << shift) - 1u));
                 const uint32_t id = ((block_lo + it) << 9) | ((uint32_t)r << 6) | (uint32_t)lane;
                 e[r] = ((uint64_t)id << 32) | low;
                 if (valid) pend |= 1u << r;
@@ -210,7 +204,7 @@ __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, 
     constexpr uint32_t ROWS = AA ? 1 : 6;
     uint64_t val[N], slot[N];
     bool valid[N];
-    uint32_t id[N];
+    uint32_t id[N], fp[N];
 #pragma unroll
     for (int k = 0; k < N; k++) {
         valid[k] = e[k] != kEntInvalid;
@@ -218,10 +212,11 @@ __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, 
         id[k] = (uint32_t)(e[k] >> 32);
         slot[k] = ((uint64_t)b << shift) | (low & ((1u << shift) - 1u));
         val[k] = (uint64_t)(low >> shift) * tab.num_sigs + slot[k];
+        fp[k] = tag_qs(low >> shift, slot[k]);
     }
     Payload pay[N];
     unsigned long long ctr_dummy = 0;
-    const uint32_t foundm = probe_n<N, COUNTERS, true>(tab, val, valid, pay, ctr_dummy, ctr_slots, slot);
+    const uint32_t foundm = probe_n<N, COUNTERS>(tab, val, slot, fp, valid, pay, ctr_dummy, ctr_slots);
     uint32_t cnt[N], rank[N], total = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -325,8 +320,8 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
             const uint32_t n = fill[(uint64_t)b * n_regions + w];
             const uint64_t *src = ent + ((uint64_t)b * n_regions + w) * cap;
             for (uint32_t c0 = g0; c0 < n && c0 < g0 + kGrab; c0 += 256u * N) {
-                uint64_t val[N], home[N], cur[N];
-                uint32_t id[N], fp[N], skip[N];
+                uint64_t home[N], cur[N];
+                uint32_t id[N], quo[N], fp[N], skip[N];
                 bool valid[N];
                 Tags16 tg[N];
 #pragma unroll
@@ -337,8 +332,8 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                     const uint32_t low = (uint32_t)e;
                     id[k] = (uint32_t)(e >> 32);
                     home[k] = ((uint64_t)b << shift) | (low & ((1u << shift) - 1u));
-                    val[k] = (uint64_t)(low >> shift) * num_sigs + home[k];
-                    fp[k] = tag_of(val[k]);
+                    quo[k] = low >> shift;
+                    fp[k] = tag_qs(quo[k], home[k]);
                     cur[k] = probe_window(home[k], &skip[k]);
                     if (valid[k]) tg[k] = load_tags(tags + cur[k]);
                 }
@@ -398,7 +393,8 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                         for (int k = 0; k < N; k++) {
                             if ((candm >> k) & 1u) {
                                 CandRec c;
-                                c.val = val[k]; c.id = id[k]; c.walked = (uint32_t)(cur[k] - home[k]);
+                                c.val = (uint64_t)quo[k] * num_sigs + home[k];          // the k-mer value, candidates only
+                                c.id = id[k]; c.walked = (uint32_t)(cur[k] - home[k]);
                                 cand[at + rank[k]] = c;
                             }
                             at += cnt[k];
@@ -428,7 +424,7 @@ __global__ __launch_bounds__(256) void verify_kernel(
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4;
     TableView tab;
-    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic;
+    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic; tab.m35 = 0;
     const unsigned long long cur = *cand_cursor;
     const uint32_t n_chunks = (uint32_t)((cur < cand_cap ? cur : cand_cap) / kUChunk);
     unsigned long long ctr_slots = 0;
@@ -441,7 +437,8 @@ __global__ __launch_bounds__(256) void verify_kernel(
             CandRec r;
             r.val = 0; r.id = 0; r.walked = 0;
             if (act) r = cand[(uint64_t)c * kUChunk + k0 + lane];
-            const uint64_t home = home_slot(r.val, tab);
+            uint64_t quo;
+            const uint64_t home = split_value(r.val, tab, &quo);
             uint64_t s = home + r.walked;
             bool found = false;
             Entry e;
@@ -450,7 +447,7 @@ __global__ __launch_bounds__(256) void verify_kernel(
                 e = load_entry(tab, s);
                 found = e.key == (int64_t)r.val;
                 if (!found) {                              // fingerprint collision: keep walking (KGJ:944-1034 semantics)
-                    const uint32_t f = tag_of(r.val);
+                    const uint32_t f = tag_qs(quo, home);
                     s += 1;
                     for (;;) {
                         if (s >= limit) { s = limit; break; }
@@ -501,7 +498,7 @@ __global__ __launch_bounds__(256) void overflow_probe_kernel(
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4;
     TableView tab;
-    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic;
+    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic; tab.m35 = 0;
     unsigned long long ctr_slots = 0;
     UListState u;
     u.base = 0; u.used = kUChunk; u.have = false;

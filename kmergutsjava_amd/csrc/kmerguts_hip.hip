@@ -106,7 +106,8 @@ struct kg_table {
     uint8_t *d_tags = nullptr;
     int64_t num_sigs = 0, entry_size = 0, version = 0;
     uint64_t limit = 0;          // complete 24-byte records present
-    uint64_t magic = 0;
+    uint64_t magic = 0;          // floor(2^64 / num_sigs)
+    uint32_t m35 = 0;            // floor(2^35 / num_sigs) when 64 <= num_sigs < 2^31 (kg::split_fast), else 0
     uint64_t occupied = 0;
     double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
     hipEvent_t ev[8] = {};
@@ -163,6 +164,7 @@ int table_finish(kg_table *t)
     unsigned __int128 one = 1;
     if (t->num_sigs == 1) t->magic = ~0ull;
     else t->magic = (uint64_t)((one << 64) / (unsigned __int128)(uint64_t)t->num_sigs);
+    t->m35 = (t->num_sigs >= 64 && t->num_sigs < (1ll << 31)) ? (uint32_t)((1ull << 35) / (uint64_t)t->num_sigs) : 0u;
     uint64_t n_tags = t->limit + kg::kTagPad;
     HIP_TRY(hipMalloc((void **)&t->d_tags, n_tags));
     unsigned long long *d_occ = nullptr;
@@ -171,7 +173,7 @@ int table_finish(kg_table *t)
     uint64_t want = (n_tags + 255) / 256;
     uint32_t grid = (uint32_t)(want < 256ull * 16 ? (want ? want : 1) : 256ull * 16);
     hipLaunchKernelGGL(kg::build_tags_kernel, dim3(grid), dim3(256), 0, t->stream, t->d_entries, t->limit, n_tags,
-                       t->d_tags, d_occ);
+                       (uint64_t)t->num_sigs, t->magic, t->d_tags, d_occ);
     HIP_TRY(hipGetLastError());
     unsigned long long occ = 0;
     HIP_TRY(hipMemcpyAsync(&occ, d_occ, 8, hipMemcpyDeviceToHost, t->stream));
@@ -485,7 +487,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                   : kg::scatter_lds_bytes<false>((uint32_t)((t->limit + (1ull << shift) - 1) >> shift)) > 160u * 1024)
             shift++;
         const uint64_t qmax = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1;
-        const bool fits = shift < 32 && qmax < (1ull << (32 - shift)) && nblocks <= (1ull << 23);
+        // the scatter pass splits k-mers with kg::split_fast: 64 <= numSigs < 2^31
+        const bool fits = shift < 32 && qmax < (1ull << (32 - shift)) && nblocks <= (1ull << 23) && t->m35 != 0;
         // Measured at 1 Gbp x 33.6 GB table (profiles/r01_partition_path.md): direct 31.9 ms; partitioned 27.1 ms
         // (scatter 13.9 + tag 10.8 + verify 2.5) with 5x less DRAM traffic.  Small inputs and L2/MALL-sized tables
         // stay on the direct kernel.  KG_PARTITION: 0 direct, 1 partitioned whenever possible, 2 (default) auto.
@@ -572,7 +575,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                 uint32_t *fill_c = d_fill + (uint64_t)c * n_regions_total;
                 uint32_t *next_c = d_next + (size_t)c * next_stride;
                 hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
-                                   d_blocks, (uint32_t)lo, nb, t->limit, (uint64_t)t->num_sigs, t->magic, part_shift, part_buckets,
+                                   d_blocks, (uint32_t)lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
                                    cap, ent_c, fill_c, d_ovfc, ovf_cap, d_ovf_bucket, d_ovf_ent, d_ctr);
                 HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
                 HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
@@ -676,7 +679,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         if (nblocks) {
             uint64_t wgs = (nblocks + kg::kWavesPerWG - 1) / kg::kWavesPerWG;
             uint32_t grid = (uint32_t)(wgs < scan_grid ? wgs : scan_grid);      // persistent waves stride over the blocks
-#define KG_SCAN_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic, d_seq, d_blocks, (uint32_t)nblocks, \
+#define KG_SCAN_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic, t->m35, d_seq, d_blocks, (uint32_t)nblocks, \
                      d_counts, d_bsb, d_stage, d_cursor, stage_cap, stage_chunk, d_ctr
 #define KG_SCAN_LAUNCH(C, R) hipLaunchKernelGGL((kg::scan_kernel<AA, C, R>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, \
                                                 t->stream, KG_SCAN_ARGS)
