@@ -334,32 +334,68 @@ __device__ __forceinline__ void encode_chars(typename WaveLds<AA>::type &l, cons
 {
     if constexpr (AA) {
         // ---- protein: windows i = 64j + lane
+        uint32_t c[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) c[k] = t.code[raw[k] & 255u];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const uint32_t q = (uint32_t)lane + 64u * k;
-            if (q < 72) l.code[q] = t.code[raw[k] & 255u];
+            if (k < 1 || q < 72) l.code[q] = c[k];
         }
         wave_sync();
-        for (uint32_t q = lane; q < 68; q += 64) l.H4[q] = half_code(l.code[q], l.code[q + 1], l.code[q + 2], l.code[q + 3]);
+        uint32_t h[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t q = min((uint32_t)lane + 64u * k, 67u);
+            h[k] = half_code(l.code[q], l.code[q + 1], l.code[q + 2], l.code[q + 3]);
+        }
+        l.H4[lane] = h[0];
+        if (lane < 4) l.H4[lane + 64] = h[1];
         wave_sync();
     } else {
         // ---- DNA: 215 bases -> base codes, codon codes for both strands, then 4-codon half codes
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[k] = t.base[raw[k] & 255u];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t q = (uint32_t)lane + 64u * k;
-            if (q < 232) l.bc[q] = t.base[raw[k] & 255u];
+            if (k < 3 || q < 232) l.bc[q] = (uint8_t)c[k];
         }
         wave_sync();
-        for (uint32_t q = lane; q < 213; q += 64) {
-            const uint32_t i = __umul24(__umul24(l.bc[q], 5u) + l.bc[q + 1], 5u) + l.bc[q + 2];
-            l.F[q] = t.fwd[i];
-            l.R[q] = t.rev[i];
+        // the four passes of each stage are unrolled with clamped reads and predicated writes, so that all LDS
+        // reads of a stage are in flight together (a wave's block is otherwise a chain of ~16 LDS round trips)
+        {
+            uint32_t i[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t q = min((uint32_t)lane + 64u * k, 212u);
+                i[k] = __umul24(__umul24(l.bc[q], 5u) + l.bc[q + 1], 5u) + l.bc[q + 2];
+            }
+            uint32_t f[4], r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { f[k] = t.fwd[i[k]]; r[k] = t.rev[i[k]]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t q = (uint32_t)lane + 64u * k;
+                if (k < 3 || q < 213) { l.F[q] = f[k]; l.R[q] = r[k]; }
+            }
         }
         wave_sync();
-        for (uint32_t q = lane; q < 204; q += 64) {
-            l.H[q] = half_code(l.F[q], l.F[q + 3], l.F[q + 6], l.F[q + 9]);
-            // on the '-' strand the codon over the highest bases comes first
-            l.G[q] = half_code(l.R[q + 9], l.R[q + 6], l.R[q + 3], l.R[q]);
+        {
+            uint32_t h[4], g[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t q = min((uint32_t)lane + 64u * k, 203u);
+                h[k] = half_code(l.F[q], l.F[q + 3], l.F[q + 6], l.F[q + 9]);
+                // on the '-' strand the codon over the highest bases comes first
+                g[k] = half_code(l.R[q + 9], l.R[q + 6], l.R[q + 3], l.R[q]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t q = (uint32_t)lane + 64u * k;
+                if (k < 3 || q < 204) { l.H[q] = h[k]; l.G[q] = g[k]; }
+            }
         }
         wave_sync();
     }

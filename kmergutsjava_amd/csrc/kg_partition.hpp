@@ -32,7 +32,10 @@
 namespace kg {
 
 constexpr int kMaxBuckets = 1024;
-constexpr int kProbeN = 4;                  // queries per lane per iteration of the bucket probe
+#ifndef KG_PROBE_N
+#define KG_PROBE_N 4
+#endif
+constexpr int kProbeN = KG_PROBE_N;                  // queries per lane per iteration of the bucket probe
 constexpr uint32_t kUChunk = 512;           // records per reservation of the unordered hit list
 
 constexpr uint64_t kEntInvalid = ~0ull;     // filler entry (padding of a 16-entry group)
@@ -44,7 +47,7 @@ inline size_t scatter_lds_bytes(uint32_t n_buckets)
 {
     size_t enc = (sizeof(typename WaveLds<AA>::type) + 15) & ~(size_t)15;
     size_t tab = (sizeof(typename WaveLds<AA>::tables) + 15) & ~(size_t)15;
-    return enc * kScatterWaves + tab + (size_t)n_buckets * (kGroup * 8 + 8);
+    return enc * kScatterWaves + tab + (size_t)n_buckets * (kGroup * 8 + 12);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -72,9 +75,10 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     uint64_t *buf = reinterpret_cast<uint64_t *>(part_lds + enc_bytes * kScatterWaves + tab_bytes);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(buf + (size_t)n_buckets * kGroup);
     uint32_t *wrel = cnt + n_buckets;                 // entries already written to this workgroup's region of bucket b
+    uint32_t *written = wrel + n_buckets;             // entries of the current group whose LDS store has been issued
     const uint32_t w = blockIdx.x, n_wg = gridDim.x;
     const uint32_t limit32 = limit < 0xFFFFFFFFull ? (uint32_t)limit : 0xFFFFFFFFu;      // slots are < num_sigs < 2^31
-    for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) { cnt[b] = 0; wrel[b] = 0; }
+    for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) { cnt[b] = 0; wrel[b] = 0; written[b] = 0; }
     encode_init<AA>(enc_tables, threadIdx.x, blockDim.x);
     __syncthreads();
 
@@ -163,23 +167,93 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 if (valid) pend |= 1u << r;
             }
             wave_sync();   // the wave's encode scratch is reused by its next block
+#if defined(KG_ABLATE) && KG_ABLATE == 1    // tuning builds only: encode + split, no insertion (results are wrong)
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) if (pend & (1u << r)) n_valid += e[r] ^ bk[r];
+            pend = 0;
+#endif
         }
-        // insert; entries that find their buffer full wait for the flush and try again.  (A spill queue that
-        // re-inserts after the flush was tried: same time, and with 16 waves a quarter of the entries spill.)
-        int more;
-        do {
+        // Insert without workgroup barriers.  A bucket's buffer is a 16-entry group with two counters:
+        //   cnt[b]      tickets: atomicAdd gives the entry's place; >= 16 means "full, try again"
+        //   written[b]  stores issued; the lane whose increment makes it 16 owns the group: it (with seven helper
+        //               lanes of its wave) copies the 128 bytes to the region, then reopens the buffer (written = 0,
+        //               then cnt = 0).  Nobody else touches buf[b] / wrel[b] between the 16th ticket and the reopening.
+        // LDS operations of one wave execute in program order and LDS is coherent in the workgroup, so the fences
+        // below only pin the compiler's order.  A lane that keeps failing waits for a flush that the owning wave
+        // performs right after its own stores; the spin guard turns a protocol bug into the host's fallback to the
+        // direct strategy (overflow > cap) instead of a hang.
+        uint32_t done = 0, spins = 0;
+        for (;;) {
             uint32_t at[ROWS];
 #pragma unroll
             for (int r = 0; r < ROWS; r++)                             // the LDS atomics of all rows in flight together
                 at[r] = (pend & (1u << r)) ? atomicAdd(&cnt[bk[r]], 1u) : kGroup;
 #pragma unroll
             for (int r = 0; r < ROWS; r++)
-                if (at[r] < kGroup) { buf[(size_t)bk[r] * kGroup + at[r]] = e[r]; pend &= ~(1u << r); }
-            __syncthreads();
-            flush_wave(kGroup);
-            more = __syncthreads_or(pend != 0);
-        } while (more);
+                if (at[r] < kGroup) buf[(size_t)bk[r] * kGroup + at[r]] = e[r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+            for (int r = 0; r < ROWS; r++)
+                if (at[r] < kGroup) {
+                    pend &= ~(1u << r);
+                    if (atomicAdd(&written[bk[r]], 1u) == kGroup - 1) done |= 1u << r;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // flush the groups completed by lanes of this wave: one per lane per pass, eight lanes per group
+            for (;;) {
+                const bool has = done != 0;
+                unsigned long long m = __ballot(has);
+                if (!m) break;
+                const int r0 = has ? __builtin_ctz(done) : 0;
+                uint32_t b = bk[0];
+#pragma unroll
+                for (int r = 1; r < ROWS; r++)
+                    if (r0 == r) b = bk[r];
+                unsigned long long dst_off = ~0ull;                    // entry index in ent (bit 62: in ovf_ent)
+                if (has) {
+                    done &= done - 1;
+                    const uint32_t rel = wrel[b];
+                    if (rel + kGroup <= cap) {
+                        dst_off = ((uint64_t)b * n_wg + w) * cap + rel;
+                        wrel[b] = rel + kGroup;
+                    } else {
+                        const uint32_t g = atomicAdd(ovf_cursor, 1u);
+                        if (g < ovf_cap) { ovf_bucket[g] = b; dst_off = (1ull << 62) | ((uint64_t)g * kGroup); }
+                        else dst_off = ~0ull - 1;                     // dropped (the host falls back to direct probing)
+                    }
+                }
+                while (m) {
+                    // the next (up to) eight flushing lanes; lane group g = lane / 8 takes the g-th of them
+                    int src_lane = -1;
+                    unsigned long long mm = m;
+#pragma unroll
+                    for (int g = 0; g < 8; g++) {
+                        const int ln = mm ? __builtin_ctzll(mm) : -1;
+                        if (mm) mm &= mm - 1;
+                        if ((lane >> 3) == g) src_lane = ln;
+                    }
+                    m = mm;
+                    const int sl = src_lane < 0 ? 0 : src_lane;
+                    const uint32_t fb = (uint32_t)__shfl((int)b, sl);
+                    const unsigned long long off = __shfl(dst_off, sl);
+                    if (src_lane >= 0 && off != ~0ull - 1) {
+                        const uint32_t sub = (uint32_t)lane & 7u;
+                        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(buf + (size_t)fb * kGroup + 2 * sub);
+                        uint64_t *base = (off >> 62) & 1 ? ovf_ent + (off & ~(1ull << 62)) : ent + off;
+                        *reinterpret_cast<ulonglong2 *>(base + 2 * sub) = v;
+                    }
+                }
+                wave_sync();                                           // the copies above read buf[b] before it reopens
+                if (has) { written[b] = 0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); cnt[b] = 0; }
+            }
+            if (!__ballot(pend != 0)) break;
+            if (++spins > (1u << 18)) {                                // never expected; see above
+                if (lane == 0) atomicAdd(ovf_cursor, ovf_cap + 1u);
+                break;
+            }
+        }
     }
+    __syncthreads();
     // partial groups, padded with fillers
     flush_wave(1u);
     __syncthreads();
@@ -324,10 +398,17 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                 uint32_t id[N], quo[N], fp[N], skip[N];
                 bool valid[N];
                 Tags16 tg[N];
+                // all entry loads first, then all tag loads: N independent L2 requests in flight per lane (loads
+                // complete in order, so interleaving entry and tag loads serialises them)
+                uint64_t ev[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) {
                     const uint32_t i = c0 + (uint32_t)k * 256u + threadIdx.x;
-                    const uint64_t e = i < n ? src[i] : kEntInvalid;
+                    ev[k] = i < n ? __builtin_nontemporal_load(src + i) : kEntInvalid;
+                }
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const uint64_t e = ev[k];
                     valid[k] = e != kEntInvalid;
                     const uint32_t low = (uint32_t)e;
                     id[k] = (uint32_t)(e >> 32);
@@ -516,17 +597,31 @@ __global__ __launch_bounds__(256) void overflow_probe_kernel(
     }
 }
 
-// counts[row] = number of hits of (block,row): one thread per (block,row)
+// ---------------------------------------------------------------------------------------
+// Ordered placement, per chunk of blocks [block_lo, block_lo + n_blocks).  A chunk starts and ends at sequence
+// boundaries, so its rows are the contiguous range [ROWS * block_lo, ROWS * (block_lo + n_blocks)) of the
+// container-major row order and its hits a contiguous range of hits[] that starts at *base (the hits of the chunks
+// before it; device memory, chained by chunk_base_kernel).  This lets chunk c be ordered while chunk c+1 is
+// still being scattered and probed.
 template <bool AA>
-__global__ void rows_from_masks_kernel(const BlockDesc *__restrict__ blocks, uint32_t n_blocks,
+__global__ void rows_from_masks_kernel(const BlockDesc *__restrict__ blocks, uint32_t block_lo, uint32_t n_blocks,
                                        const unsigned long long *__restrict__ masks, uint32_t *__restrict__ counts)
 {
     constexpr uint32_t ROWS = AA ? 1 : 6;
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint64_t)n_blocks * ROWS) return;
+    const uint64_t tl = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tl >= (uint64_t)n_blocks * ROWS) return;
+    const uint64_t t = (uint64_t)block_lo * ROWS + tl;
     const uint32_t it = (uint32_t)(t / ROWS), r = (uint32_t)(t % ROWS);
     const BlockDesc bd = blocks[it];
     counts[row_index<AA>(bd, it, (int)r)] = (uint32_t)__popcll(masks[t]);
+}
+
+// base[1] = base[0] + *chunk_total; the last chunk also publishes the grand total
+__global__ void chunk_base_kernel(const uint64_t *chunk_total, uint64_t *base, uint64_t *grand_total)
+{
+    const uint64_t b = base[0] + *chunk_total;
+    base[1] = b;
+    if (grand_total) *grand_total = b;
 }
 
 // One 24-byte record per (block,row): everything the placement of a hit needs, so that it costs one random line
@@ -540,34 +635,41 @@ struct RowInfo {
 };
 static_assert(sizeof(RowInfo) == 24, "RowInfo must be 24 bytes");
 
+// offs[] holds the chunk-local exclusive prefix on entry and the global one on return
 template <bool AA>
-__global__ void row_info_kernel(const BlockDesc *__restrict__ blocks, uint32_t n_blocks,
-                                const unsigned long long *__restrict__ masks, const uint32_t *__restrict__ offs,
-                                RowInfo *__restrict__ info)
+__global__ void row_info_kernel(const BlockDesc *__restrict__ blocks, uint32_t block_lo, uint32_t n_blocks,
+                                const unsigned long long *__restrict__ masks, uint32_t *__restrict__ offs,
+                                const uint64_t *__restrict__ base, RowInfo *__restrict__ info)
 {
     constexpr uint32_t ROWS = AA ? 1 : 6;
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint64_t)n_blocks * ROWS) return;
+    const uint64_t tl = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tl >= (uint64_t)n_blocks * ROWS) return;
+    const uint64_t t = (uint64_t)block_lo * ROWS + tl;
     const uint32_t it = (uint32_t)(t / ROWS), r = (uint32_t)(t % ROWS);
     const BlockDesc bd = blocks[it];
+    const uint32_t row = row_index<AA>(bd, it, (int)r);
     RowInfo ri;
     ri.mask = masks[t];
-    ri.off = offs[row_index<AA>(bd, it, (int)r)];
+    ri.off = (uint32_t)*base + offs[row];
+    offs[row] = ri.off;
     row_record_key<AA>(bd, (int)r, 0, &ri.container, &ri.pos0);
     ri.step = (!AA && r >= 3) ? -1 : 1;
     info[t] = ri;
 }
 
-// unordered list -> hits[] ordered by (container, from0InProt); one workgroup per reservation chunk
+// unordered list -> hits[] ordered by (container, from0InProt); one workgroup per reservation chunk of the list
+// (the grid covers the list's capacity; workgroups beyond the cursor leave)
 template <bool AA>
 __global__ __launch_bounds__(256) void place_unordered_kernel(const RowInfo *__restrict__ info,
                                                               const kg_hit *__restrict__ ulist,
-                                                              const uint32_t *__restrict__ chunk_used, uint32_t n_chunks,
-                                                              kg_hit *__restrict__ hits)
+                                                              const uint32_t *__restrict__ chunk_used,
+                                                              const unsigned long long *__restrict__ cursor, uint64_t ulist_cap,
+                                                              kg_hit *__restrict__ hits, uint64_t hits_cap)
 {
     constexpr uint32_t ROWS = AA ? 1 : 6;
     const uint32_t c = blockIdx.x;
-    if (c >= n_chunks) return;
+    const unsigned long long cur = *cursor;
+    if ((uint64_t)c >= (cur < ulist_cap ? cur : ulist_cap) / kUChunk) return;
     const uint32_t used = chunk_used[c];
     for (uint32_t k = threadIdx.x; k < used; k += blockDim.x) {
         kg_hit h = ulist[(uint64_t)c * kUChunk + k];
@@ -578,7 +680,8 @@ __global__ __launch_bounds__(256) void place_unordered_kernel(const RowInfo *__r
         const unsigned long long before = ri.step < 0 ? (ln == 63 ? 0ull : (ri.mask >> (ln + 1))) : (ri.mask & ((1ull << ln) - 1ull));
         h.container = ri.container;
         h.from0InProt = ri.pos0 + ri.step * (int32_t)ln;
-        hits[(uint64_t)ri.off + (uint32_t)__popcll(before)] = h;
+        const uint64_t dst = (uint64_t)ri.off + (uint32_t)__popcll(before);
+        if (dst < hits_cap) hits[dst] = h;       // only out of range when a list overflowed: that scan is re-run
     }
 }
 

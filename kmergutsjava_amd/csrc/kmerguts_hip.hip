@@ -370,13 +370,15 @@ void kg_result_free(kg_result *r)
 namespace {
 
 // exclusive prefix sum of d_in[n] -> d_out[n], total -> d_total (device uint64)
-int prefix_sum(kg_table *t, const uint32_t *d_in, uint64_t n, uint32_t *d_out, uint64_t *d_partial, uint64_t *d_total)
+int prefix_sum(kg_table *t, const uint32_t *d_in, uint64_t n, uint32_t *d_out, uint64_t *d_partial, uint64_t *d_total,
+               hipStream_t stream = nullptr)
 {
+    if (!stream) stream = t->stream;
     uint32_t nb = (uint32_t)((n + kg::kScanChunk - 1) / kg::kScanChunk);
     if (nb == 0) nb = 1;
-    hipLaunchKernelGGL(kg::scan_partials_kernel, dim3(nb), dim3(kg::kScanThreads), 0, t->stream, d_in, n, d_partial);
-    hipLaunchKernelGGL(kg::scan_top_kernel, dim3(1), dim3(kg::kScanThreads), 0, t->stream, d_partial, nb, d_total);
-    hipLaunchKernelGGL(kg::scan_final_kernel, dim3(nb), dim3(kg::kScanThreads), 0, t->stream, d_in, n, d_partial, d_out);
+    hipLaunchKernelGGL(kg::scan_partials_kernel, dim3(nb), dim3(kg::kScanThreads), 0, stream, d_in, n, d_partial);
+    hipLaunchKernelGGL(kg::scan_top_kernel, dim3(1), dim3(kg::kScanThreads), 0, stream, d_partial, nb, d_total);
+    hipLaunchKernelGGL(kg::scan_final_kernel, dim3(nb), dim3(kg::kScanThreads), 0, stream, d_in, n, d_partial, d_out);
     HIP_TRY(hipGetLastError());
     return KG_OK;
 }
@@ -501,15 +503,30 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
     bool part_done = false;
     if (use_part) {
         constexpr uint32_t WIN = AA ? 64u : 384u;                                    // windows per block
+        constexpr uint32_t kMaxChunks = 8;
         const uint32_t per_iter = kg::kScatterWaves;
-        // The batch is cut into chunks of blocks; chunk c+1 is scattered (stream) while chunk c is probed (stream2):
-        // the scatter pass is LDS/issue-bound with one 16-wave workgroup per CU, the tag pass is L2-bound with few
-        // registers and no LDS, so the two share the CUs.
-        uint32_t n_chunks_p = env_u32("KG_PART_CHUNKS", 4u);
-        if (n_chunks_p < 1) n_chunks_p = 1;
-        if (n_chunks_p > 8) n_chunks_p = 8;
-        while (n_chunks_p > 1 && nblocks / n_chunks_p < 64ull * 1024) n_chunks_p--;
-        const uint64_t chunk_blocks = ((nblocks + n_chunks_p - 1) / n_chunks_p + per_iter - 1) / per_iter * per_iter;
+        // The batch is cut into chunks of whole sequences.  Chunk c goes through scatter (stream), then tag pass,
+        // verification and ordered placement (stream2) while chunk c+1 is scattered: the scatter pass is LDS/issue-
+        // bound with one 16-wave workgroup per CU, the tag pass is L2-bound with few registers and no LDS, verification
+        // and placement wait on random HBM lines, so they share the CUs.  A chunk's hits are a contiguous range of
+        // hits[] (whole sequences), chained by a device-side running total.
+        uint32_t want = env_u32("KG_PART_CHUNKS", 4u);
+        if (want < 1) want = 1;
+        if (want > kMaxChunks) want = kMaxChunks;
+        while (want > 1 && nblocks / want < 64ull * 1024) want--;
+        std::vector<uint64_t> clo;                                                    // chunk c = blocks [clo[c], clo[c+1])
+        clo.push_back(0);
+        for (uint32_t c = 1; c < want; c++) {
+            const uint64_t target = nblocks * c / want;
+            const uint64_t cut = *std::lower_bound(ibase.begin(), ibase.end(), (uint32_t)target);   // a sequence start
+            if (cut > clo.back() && cut < nblocks) clo.push_back(cut);
+        }
+        clo.push_back(nblocks);
+        const uint32_t n_chunks_p = (uint32_t)clo.size() - 1;
+        uint64_t max_chunk = 0;
+        for (uint32_t c = 0; c < n_chunks_p; c++) max_chunk = std::max(max_chunk, clo[c + 1] - clo[c]);
+        const uint64_t chunk_blocks = (max_chunk + per_iter - 1) / per_iter * per_iter;
+        const double max_frac = (double)max_chunk / (double)nblocks;
         uint32_t n_wg = env_u32("KG_PART_WGS", 256u);
         if ((uint64_t)n_wg * per_iter > chunk_blocks) n_wg = (uint32_t)((chunk_blocks + per_iter - 1) / per_iter);
         const uint64_t blocks_per_wg = ((chunk_blocks + (uint64_t)n_wg * per_iter - 1) / ((uint64_t)n_wg * per_iter)) * per_iter;
@@ -517,126 +534,155 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         const double mean = (double)blocks_per_wg * WIN / (double)part_buckets * (env_u32("KG_PART_SLACK", 100u) / 100.0);
         const uint32_t cap = (uint32_t)(((uint64_t)(mean + 6.0 * std::sqrt(mean) + 32.0) + 15) / 16 * 16);
         const uint64_t n_regions_total = (uint64_t)part_buckets * n_wg;               // per chunk
-        const uint32_t ovf_cap = env_u32("KG_PART_OVF_GROUPS", (uint32_t)std::min<uint64_t>(1u << 22, std::max<uint64_t>(4096, n_regions_total * n_chunks_p * cap / 16 / 64)));
+        // overflow list of one chunk (groups)
+        const uint32_t ovf_cap = env_u32("KG_PART_OVF_GROUPS", (uint32_t)std::min<uint64_t>(1u << 21, std::max<uint64_t>(4096, n_regions_total * cap / 16 / 64)));
         uint64_t *d_ent = nullptr, *d_ovf_ent = nullptr;
         uint32_t *d_fill = nullptr, *d_ovf_bucket = nullptr, *d_next = nullptr, *d_ovfc = nullptr;
         unsigned long long *d_masks = nullptr;
+        kg::RowInfo *d_info = nullptr;
+        uint64_t *d_pc = nullptr;            // [0..7] hit-list cursors, [8..15] candidate cursors, [16..24] base, [32..39] chunk totals
+        uint64_t *d_partial_c = nullptr;
+        const size_t partial_stride = (size_t)(chunk_blocks * PER / kg::kScanChunk + 2);
         if ((rc = sc.get(&d_ent, (size_t)(n_regions_total * cap * n_chunks_p)))) return rc;
         if ((rc = sc.get(&d_fill, (size_t)n_regions_total * n_chunks_p))) return rc;
-        if ((rc = sc.get(&d_ovf_ent, (size_t)ovf_cap * kg::kGroup))) return rc;
-        if ((rc = sc.get(&d_ovf_bucket, (size_t)ovf_cap))) return rc;
+        if ((rc = sc.get(&d_ovf_ent, (size_t)ovf_cap * kg::kGroup * n_chunks_p))) return rc;
+        if ((rc = sc.get(&d_ovf_bucket, (size_t)ovf_cap * n_chunks_p))) return rc;
         const size_t next_stride = (size_t)part_buckets + 8;
         if ((rc = sc.get(&d_next, next_stride * n_chunks_p))) return rc;
-        if ((rc = sc.get(&d_ovfc, 8))) return rc;
+        if ((rc = sc.get(&d_ovfc, 8 * kMaxChunks))) return rc;
         if ((rc = sc.get(&d_masks, (size_t)n_rows))) return rc;
-        unsigned long long *d_cursor = (unsigned long long *)(d_totals + 1);
+        if ((rc = sc.get(&d_info, (size_t)n_rows))) return rc;
+        if ((rc = sc.get(&d_pc, 48))) return rc;
+        if ((rc = sc.get(&d_partial_c, partial_stride * n_chunks_p))) return rc;
         unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
         HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
-        HIP_TRY(hipMemsetAsync(d_masks, 0, n_rows * 8, t->stream));
         const size_t lds = kg::scatter_lds_bytes<AA>(part_buckets);
         HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 4u) & ~7u;
-        uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio) + (uint64_t)(probe_grid + 64) * 4 * kg::kUChunk * n_chunks_p + 4096 +
-                         kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
+        const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
+        // per-chunk lists: hits (unordered) and candidates = fingerprint matches (hits + ~0.4 % of the probes)
+        const uint64_t list_slack = (uint64_t)(std::max(probe_grid, verify_grid) + 64) * 4 * kg::kUChunk + 4096;
+        uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio * max_frac) + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
+        uint64_t ccap = ((uint64_t)((double)windows * (t->stage_ratio * 1.25 + 0.01) * max_frac) + list_slack + kg::kUChunk - 1) /
+                        kg::kUChunk * kg::kUChunk;
         kg_hit *d_ulist = nullptr;
         uint32_t *d_cused = nullptr, *d_candused = nullptr;
         kg::CandRec *d_cand = nullptr;
-        uint64_t n_chunks = 0;
         bool too_skewed = false;
-        // candidates = fingerprint matches (hits + ~0.4 % of the probes): a little above the hit list
-        uint64_t ccap = ((uint64_t)((double)windows * (t->stage_ratio * 1.25 + 0.01)) + (uint64_t)probe_grid * 4 * kg::kUChunk * n_chunks_p +
-                         4096 + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
-        unsigned long long *d_ccursor = (unsigned long long *)(d_totals + 6);
-        const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
         const uint32_t grab_unit = 256u * kg::kProbeN;
         const uint32_t probe_grab = (std::max(env_u32("KG_PROBE_GRAB", cap), grab_unit) + grab_unit - 1) / grab_unit * grab_unit;
         HIP_TRY(hipEventRecord(t->ev[1], t->stream));
         for (int attempt = 0; attempt < 3; attempt++) {
-            if ((rc = dalloc(t, (void **)&d_ulist, ucap * sizeof(kg_hit)))) return rc;
-            if ((rc = dalloc(t, (void **)&d_cused, (ucap / kg::kUChunk + 1) * 4))) { sc.adopt(d_ulist); return rc; }
-            if ((rc = dalloc(t, (void **)&d_cand, ccap * sizeof(kg::CandRec)))) { sc.adopt(d_ulist); sc.adopt(d_cused); return rc; }
-            if ((rc = dalloc(t, (void **)&d_candused, (ccap / kg::kUChunk + 1) * 4))) { sc.adopt(d_ulist); sc.adopt(d_cused); sc.adopt(d_cand); return rc; }
-            HIP_TRY(hipMemsetAsync(d_cused, 0, (ucap / kg::kUChunk + 1) * 4, t->stream));
-            HIP_TRY(hipMemsetAsync(d_candused, 0, (ccap / kg::kUChunk + 1) * 4, t->stream));
-            HIP_TRY(hipMemsetAsync(d_cursor, 0, 8, t->stream));
-            HIP_TRY(hipMemsetAsync(d_ccursor, 0, 8, t->stream));
-            HIP_TRY(hipMemsetAsync(d_totals + 2, 0, 16, t->stream));      // both counters of a re-run start over
-            HIP_TRY(hipMemsetAsync(d_ovfc, 0, 32, t->stream));
+            const uint64_t hits_cap = ucap * n_chunks_p;
+            const size_t cused_stride = (size_t)(ucap / kg::kUChunk + 1), candused_stride = (size_t)(ccap / kg::kUChunk + 1);
+            if ((rc = dalloc(t, (void **)&res->d_hits, hits_cap * sizeof(kg_hit)))) return rc;
+            if ((rc = dalloc(t, (void **)&d_ulist, ucap * n_chunks_p * sizeof(kg_hit)))) return rc;
+            if ((rc = dalloc(t, (void **)&d_cused, cused_stride * n_chunks_p * 4))) { sc.adopt(d_ulist); return rc; }
+            if ((rc = dalloc(t, (void **)&d_cand, ccap * n_chunks_p * sizeof(kg::CandRec)))) { sc.adopt(d_ulist); sc.adopt(d_cused); return rc; }
+            if ((rc = dalloc(t, (void **)&d_candused, candused_stride * n_chunks_p * 4))) { sc.adopt(d_ulist); sc.adopt(d_cused); sc.adopt(d_cand); return rc; }
+            HIP_TRY(hipMemsetAsync(d_cused, 0, cused_stride * n_chunks_p * 4, t->stream));
+            HIP_TRY(hipMemsetAsync(d_candused, 0, candused_stride * n_chunks_p * 4, t->stream));
+            HIP_TRY(hipMemsetAsync(d_pc, 0, 48 * 8, t->stream));
+            HIP_TRY(hipMemsetAsync(d_totals, 0, 32, t->stream));          // total and both counters of a re-run start over
+            HIP_TRY(hipMemsetAsync(d_ovfc, 0, 8 * kMaxChunks * 4, t->stream));
             HIP_TRY(hipMemsetAsync(d_next, 0, next_stride * n_chunks_p * 4, t->stream));
+            HIP_TRY(hipMemsetAsync(d_masks, 0, n_rows * 8, t->stream));
             HIP_TRY(hipEventRecord(t->pev[16], t->stream));               // fork: stream2 starts behind the clears
             HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[16], 0));
 #define KG_PROBE_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic
-#define KG_ULIST_ARGS d_ulist, d_cused, d_cursor, ucap, d_masks, d_ctr
             for (uint32_t c = 0; c < n_chunks_p; c++) {
-                const uint64_t lo = (uint64_t)c * chunk_blocks;
-                if (lo >= nblocks) break;
-                const uint32_t nb = (uint32_t)std::min<uint64_t>(chunk_blocks, nblocks - lo);
+                const uint32_t lo = (uint32_t)clo[c], nb = (uint32_t)(clo[c + 1] - clo[c]);
                 uint64_t *ent_c = d_ent + (uint64_t)c * n_regions_total * cap;
                 uint32_t *fill_c = d_fill + (uint64_t)c * n_regions_total;
                 uint32_t *next_c = d_next + (size_t)c * next_stride;
+                uint32_t *ovfc_c = d_ovfc + 8 * c, *ovf_bucket_c = d_ovf_bucket + (size_t)c * ovf_cap;
+                uint64_t *ovf_ent_c = d_ovf_ent + (size_t)c * ovf_cap * kg::kGroup;
+                kg_hit *ulist_c = d_ulist + (uint64_t)c * ucap;
+                uint32_t *cused_c = d_cused + c * cused_stride, *candused_c = d_candused + c * candused_stride;
+                kg::CandRec *cand_c = d_cand + (uint64_t)c * ccap;
+                unsigned long long *ucur_c = (unsigned long long *)(d_pc + c), *ccur_c = (unsigned long long *)(d_pc + 8 + c);
+                uint64_t *base_c = d_pc + 16 + c, *ctot_c = d_pc + 32 + c;
                 hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
-                                   d_blocks, (uint32_t)lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
-                                   cap, ent_c, fill_c, d_ovfc, ovf_cap, d_ovf_bucket, d_ovf_ent, d_ctr);
+                                   d_blocks, lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
+                                   cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, d_ctr);
                 HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
                 HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
-#define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, d_cand, \
-                    d_candused, d_ccursor, ccap, d_ctr
-                if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, t->stream2, KG_TAG_ARGS);
-                else hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, t->stream2, KG_TAG_ARGS);
+                hipStream_t s2 = t->stream2;
+#define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
+                    candused_c, ccur_c, ccap, d_ctr
+#define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_masks, d_ctr
+                if (counters) {
+                    hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
+                    hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, s2, KG_PROBE_ARGS, cand_c,
+                                       candused_c, ccur_c, ccap, KG_ULIST_ARGS);
+                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(64), dim3(256), 0, s2, KG_PROBE_ARGS,
+                                       ovf_bucket_c, ovf_ent_c, ovfc_c, ovf_cap, part_shift, KG_ULIST_ARGS);
+                } else {
+                    hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
+                    hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, s2, KG_PROBE_ARGS, cand_c,
+                                       candused_c, ccur_c, ccap, KG_ULIST_ARGS);
+                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(64), dim3(256), 0, s2, KG_PROBE_ARGS,
+                                       ovf_bucket_c, ovf_ent_c, ovfc_c, ovf_cap, part_shift, KG_ULIST_ARGS);
+                }
 #undef KG_TAG_ARGS
-            }
-            HIP_TRY(hipEventRecord(t->ev[5], t->stream));                 // all chunks scattered
-            // candidates of all chunks are verified once the last tag pass is done
-            if (counters) {
-                hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, t->stream2, KG_PROBE_ARGS, d_cand,
-                                   d_candused, d_ccursor, ccap, KG_ULIST_ARGS);
-                hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(64), dim3(256), 0, t->stream2, KG_PROBE_ARGS,
-                                   d_ovf_bucket, d_ovf_ent, d_ovfc, ovf_cap, part_shift, KG_ULIST_ARGS);
-            } else {
-                hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, t->stream2, KG_PROBE_ARGS, d_cand,
-                                   d_candused, d_ccursor, ccap, KG_ULIST_ARGS);
-                hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(64), dim3(256), 0, t->stream2, KG_PROBE_ARGS,
-                                   d_ovf_bucket, d_ovf_ent, d_ovfc, ovf_cap, part_shift, KG_ULIST_ARGS);
+#undef KG_ULIST_ARGS
+                // ordered placement of the chunk's hits
+                const uint64_t rows_c = (uint64_t)nb * PER, row_lo = (uint64_t)lo * PER;
+                const uint32_t rgrid = (uint32_t)((rows_c + 255) / 256);
+                hipLaunchKernelGGL((kg::rows_from_masks_kernel<AA>), dim3(rgrid), dim3(256), 0, s2, d_blocks, lo, nb, d_masks, d_counts);
+                if ((rc = prefix_sum(t, d_counts + row_lo, rows_c, d_offs + row_lo, d_partial_c + c * partial_stride, ctot_c, s2))) return rc;
+                hipLaunchKernelGGL(kg::chunk_base_kernel, dim3(1), dim3(1), 0, s2, ctot_c, base_c,
+                                   c + 1 == n_chunks_p ? d_totals : (uint64_t *)nullptr);
+                hipLaunchKernelGGL((kg::row_info_kernel<AA>), dim3(rgrid), dim3(256), 0, s2, d_blocks, lo, nb, d_masks, d_offs, base_c,
+                                   d_info);
+                hipLaunchKernelGGL((kg::place_unordered_kernel<AA>), dim3((uint32_t)(ucap / kg::kUChunk)), dim3(256), 0, s2, d_info,
+                                   ulist_c, cused_c, ucur_c, ucap, res->d_hits, hits_cap);
+                HIP_TRY(hipGetLastError());
+                if (c + 1 == n_chunks_p) HIP_TRY(hipEventRecord(t->ev[5], t->stream));   // all chunks scattered
             }
 #undef KG_PROBE_ARGS
-#undef KG_ULIST_ARGS
-            HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(t->pev[17], t->stream2));              // join
             HIP_TRY(hipStreamWaitEvent(t->stream, t->pev[17], 0));
             HIP_TRY(hipEventRecord(t->ev[7], t->stream));
             st.scan_launches++;
-            uint64_t h_cur = 0, h_ccur = 0;
-            uint32_t h_ovf = 0;
-            HIP_TRY(hipMemcpyAsync(&h_cur, d_cursor, 8, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipMemcpyAsync(&h_ccur, d_ccursor, 8, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipMemcpyAsync(&h_ovf, d_ovfc, 4, hipMemcpyDeviceToHost, t->stream));
+            uint64_t h_pc[48];
+            uint32_t h_ovf[8 * kMaxChunks];
+            HIP_TRY(hipMemcpyAsync(h_pc, d_pc, sizeof h_pc, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(h_ovf, d_ovfc, sizeof h_ovf, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
+            uint64_t need_u = 0, need_c = 0;
+            uint32_t max_ovf = 0;
+            for (uint32_t c = 0; c < n_chunks_p; c++) {
+                need_u = std::max(need_u, h_pc[c]); need_c = std::max(need_c, h_pc[8 + c]);
+                max_ovf = std::max(max_ovf, h_ovf[8 * c]);
+            }
             if (getenv("KG_DEBUG"))
-                fprintf(stderr, "[kg] partition attempt %d: %u chunks, overflow groups %u (cap %u), hit list %llu (cap %llu), candidates %llu "
-                                "(cap %llu), regions/chunk %llu x %u entries, %u buckets, shift %u, %u scatter workgroups\n",
-                        attempt, n_chunks_p, h_ovf, ovf_cap, (unsigned long long)h_cur, (unsigned long long)ucap, (unsigned long long)h_ccur,
-                        (unsigned long long)ccap, (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg);
-            if (h_ovf > ovf_cap) { too_skewed = true; break; }           // more overflow than provisioned: direct path
-            n_chunks = h_cur / kg::kUChunk;
-            if (h_cur <= ucap && h_ccur <= ccap) break;
-            // a list was too small: now the exact need is known (masks are idempotent: the re-run sets the same bits)
-            dfree(t, d_ulist); dfree(t, d_cused); dfree(t, d_cand); dfree(t, d_candused);     // both streams are idle here
-            d_ulist = nullptr; d_cused = nullptr; d_cand = nullptr; d_candused = nullptr;
+                fprintf(stderr, "[kg] partition attempt %d: %u chunks (largest %llu of %llu blocks), overflow groups <= %u (cap %u), hit list <= %llu "
+                                "(cap %llu), candidates <= %llu (cap %llu), regions/chunk %llu x %u entries, %u buckets, shift %u, %u scatter "
+                                "workgroups, hits %llu\n",
+                        attempt, n_chunks_p, (unsigned long long)max_chunk, (unsigned long long)nblocks, max_ovf, ovf_cap,
+                        (unsigned long long)need_u, (unsigned long long)ucap, (unsigned long long)need_c, (unsigned long long)ccap,
+                        (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg, (unsigned long long)h_pc[16 + n_chunks_p]);
+            if (max_ovf > ovf_cap) { too_skewed = true; break; }         // more overflow than provisioned: direct path
+            n_hits = h_pc[16 + n_chunks_p];
+            if (need_u <= ucap && need_c <= ccap) break;
+            // a list was too small: now the exact need is known (masks are cleared and everything is redone)
+            dfree(t, d_ulist); dfree(t, d_cused); dfree(t, d_cand); dfree(t, d_candused); dfree(t, res->d_hits);   // both streams are idle
+            d_ulist = nullptr; d_cused = nullptr; d_cand = nullptr; d_candused = nullptr; res->d_hits = nullptr;
             if (attempt == 2) return fail(KG_ERR_DEVICE, "hit list overflow after resize (internal error)");
-            if (h_ccur > ccap) { ccap = h_ccur; ucap = std::max<uint64_t>(ucap, h_ccur); }     // hits <= candidates
-            else ucap = h_cur;
+            if (need_c > ccap) { ccap = (need_c + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk; ucap = std::max(ucap, ccap); }   // hits <= candidates
+            else ucap = (need_u + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         }
         sc.adopt(d_cand); sc.adopt(d_candused);
         sc.adopt(d_ulist); sc.adopt(d_cused);
-        if (!too_skewed) {
+        if (too_skewed) {
+            dfree(t, res->d_hits);
+            res->d_hits = nullptr;
+        } else {
             HIP_TRY(hipEventRecord(t->ev[2], t->stream));
-            hipLaunchKernelGGL((kg::rows_from_masks_kernel<AA>), dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, t->stream,
-                               d_blocks, (uint32_t)nblocks, d_masks, d_counts);
-            if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) return rc;
             uint64_t h_tot[4] = {0, 0, 0, 0};
             HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 32, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
-            n_hits = h_tot[0];
             st.windows_valid = counters ? (int64_t)h_tot[2] : -1;
             st.slots_inspected = counters ? (int64_t)h_tot[3] : -1;
             if (windows) {
@@ -644,15 +690,6 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                 if (ratio > t->stage_ratio) t->stage_ratio = ratio > 1.0 ? 1.0 : ratio;
             }
             st.n_hits = (int64_t)n_hits;
-            if ((rc = dalloc(t, (void **)&res->d_hits, n_hits * sizeof(kg_hit)))) return rc;
-            if (n_chunks) {
-                kg::RowInfo *d_info = nullptr;
-                if ((rc = sc.get(&d_info, (size_t)n_rows))) return rc;
-                hipLaunchKernelGGL((kg::row_info_kernel<AA>), dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, t->stream,
-                                   d_blocks, (uint32_t)nblocks, d_masks, d_offs, d_info);
-                hipLaunchKernelGGL((kg::place_unordered_kernel<AA>), dim3((uint32_t)n_chunks), dim3(256), 0, t->stream, d_info,
-                                   d_ulist, d_cused, (uint32_t)n_chunks, res->d_hits);
-            }
             part_done = true;
             st.partitioned = 1;
         }

@@ -35,7 +35,7 @@ def _partition_fits(stats) -> bool:
     while ((num_sigs + (1 << shift) - 1) >> shift) > 1024:
         shift += 1
     enc = 3632 * 16 + 1280 if stats["n_containers"] != stats["n_seqs"] else 640 * 16 + 1024   # WaveLds<AA> x 16 + tables
-    while enc + ((num_sigs + (1 << shift) - 1) >> shift) * 136 > 160 * 1024:
+    while enc + ((num_sigs + (1 << shift) - 1) >> shift) * 140 > 160 * 1024:
         shift += 1
     qmax = 20 ** 8 // num_sigs + 1
     return shift < 32 and qmax < (1 << (32 - shift)) and stats["n_blocks"] <= (1 << 23) and 64 <= num_sigs < (1 << 31)

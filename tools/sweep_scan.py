@@ -16,11 +16,14 @@ lens = synth.contig_mix_lengths(total_bp, 301); off = synth.offsets_of(lens)
 seq = synth.random_dna(int(off[-1]), 302, dev)
 torch.cuda.synchronize()
 variants = [dict(KG_PARTITION=0)]
-for qg in (1024, 1792, 2048, 3584):
-    variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=21, KG_PROBE_GRID=qg, KG_VERIFY_GRID=2048))
-for shift in (20, 22):
-    variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=shift, KG_PROBE_GRID=1792, KG_VERIFY_GRID=2048))
-variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=21, KG_PROBE_GRID=1792, KG_VERIFY_GRID=4096))
+if os.environ.get("SW_VARIANTS"):            # e.g. SW_VARIANTS='[{"KG_PROBE_GRID": 2048}, ...]' (KG_PARTITION=1 implied)
+    variants = [dict(dict(KG_PARTITION=1), **v) for v in json.loads(os.environ["SW_VARIANTS"])]
+else:
+    for qg in (1024, 1792, 2048, 3584):
+        variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=21, KG_PROBE_GRID=qg, KG_VERIFY_GRID=2048))
+    for shift in (20, 22):
+        variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=shift, KG_PROBE_GRID=1792, KG_VERIFY_GRID=2048))
+    variants.append(dict(KG_PARTITION=1, KG_PART_SHIFT=21, KG_PROBE_GRID=1792, KG_VERIFY_GRID=4096))
 ref = None
 for v in variants:
     for k, x in v.items():
@@ -40,4 +43,5 @@ for v in variants:
     assert sig == ref, (sig, ref)
     print(json.dumps(dict(v, ms_scan=best["ms_scan"], ms_order=best["ms_order"], ms_aggregate=best["ms_aggregate"],
                           ms_total=best["ms_total"], wall_ms=best["wall_ms"], launches=best["scan_launches"],
-                          n_hits=best["n_hits"])), flush=True)
+                          n_hits=best["n_hits"], part_scatter=best.get("ms_part_scatter"), part_tail=best.get("ms_part_verify"),
+                          lib=os.environ.get("KG_LIB_PATH", ""))), flush=True)
