@@ -334,7 +334,8 @@ __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, 
 //                 becomes a 16-byte candidate record {value, id, slots walked}.  Never touches the 24-byte records.
 //   verify pass : one lane per candidate: fetch the record (random line from HBM, thousands in flight), compare the
 //                 key, emit the hit; a fingerprint collision keeps walking (generic, rare).
-struct CandRec { uint64_t val; uint32_t id; uint32_t walked; };
+struct CandRec { uint64_t val; uint32_t id; uint32_t walked; };   // walked: slots from the home slot; kWalkOn: no record to check yet
+constexpr uint32_t kWalkOn = 0x80000000u;
 static_assert(sizeof(CandRec) == 16, "CandRec must be 16 bytes");
 
 // reserve `total` (<= kUChunk) consecutive records of a chunked list for this wave; ~0 when the list is full
@@ -367,7 +368,8 @@ template <bool COUNTERS>
 __global__ __launch_bounds__(256) void bucket_tag_kernel(
     const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, const uint64_t *__restrict__ ent,
     const uint32_t *__restrict__ fill, uint32_t n_regions, uint32_t cap, uint32_t n_buckets, uint32_t shift,
-    uint32_t grab /* entry slots per hand-out, multiple of 256 * kProbeN */, uint32_t *next_region /* [n_buckets], zeroed */,
+    uint32_t grab /* entry slots per hand-out, multiple of 256 * kProbeN */,
+    uint32_t *next_region /* [n_buckets], zeroed */,
     CandRec *__restrict__ cand, uint32_t *__restrict__ cand_used, unsigned long long *cand_cursor, uint64_t cand_cap,
     unsigned long long *ctr)
 {
@@ -418,44 +420,19 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                     cur[k] = probe_window(home[k], &skip[k]);
                     if (valid[k]) tg[k] = load_tags(tags + cur[k]);
                 }
-                uint32_t candm = 0, pend = 0;
+                // a window that holds neither an empty slot nor the fingerprint (2 % of the probes: straddling windows,
+                // long clusters) is not walked here: it goes to the candidate list with kWalkOn set and the verify pass
+                // continues the walk.  This keeps the hot loop free of the generic walk.
+                uint32_t candm = 0, walkm = 0;
 #pragma unroll
                 for (int k = 0; k < N; k++) {
                     if (valid[k]) {
                         bool emp;
                         const int i = first_stop(tg[k], fp[k], &emp, skip[k]);
-                        if (i == 16) { pend |= 1u << k; cur[k] += 16; }
-                        else {
-                            cur[k] += (uint64_t)i;
-                            if (!emp) candm |= 1u << k;
-                            else if (COUNTERS) ctr_slots += (cur[k] < limit ? cur[k] + 1 : limit) - home[k];
-                        }
-                    }
-                }
-                while (__ballot(pend != 0)) {            // walks longer than 16 slots (rare), tags only
-                    if (pend) {
-                        const int r = __builtin_ctz(pend);
-                        uint64_t sl = cur[0], hm = home[0];
-                        uint32_t f = fp[0];
-#pragma unroll
-                        for (int k = 1; k < N; k++)
-                            if (r == k) { sl = cur[k]; f = fp[k]; hm = home[k]; }
-                        bool done = false, is_cand = false;
-                        if (sl >= limit) { done = true; sl = limit; }
-                        else {
-                            const Tags16 x = load_tags(tags + sl);
-                            bool emp;
-                            const int i = first_stop(x, f, &emp);
-                            if (i == 16) sl += 16;
-                            else { sl += (uint64_t)i; done = true; is_cand = !emp; }
-                        }
-#pragma unroll
-                        for (int k = 0; k < N; k++)
-                            if (r == k) { cur[k] = sl; if (is_cand) candm |= 1u << k; }
-                        if (done) {
-                            pend &= pend - 1;
-                            if (COUNTERS && !is_cand) ctr_slots += (sl < limit ? sl + 1 : limit) - hm;
-                        }
+                        cur[k] += (uint64_t)i;
+                        if (i == 16) { candm |= 1u << k; walkm |= 1u << k; }
+                        else if (!emp) candm |= 1u << k;
+                        else if (COUNTERS) ctr_slots += (cur[k] < limit ? cur[k] + 1 : limit) - home[k];
                     }
                 }
                 // candidates -> list
@@ -475,7 +452,7 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                             if ((candm >> k) & 1u) {
                                 CandRec c;
                                 c.val = (uint64_t)quo[k] * num_sigs + home[k];          // the k-mer value, candidates only
-                                c.id = id[k]; c.walked = (uint32_t)(cur[k] - home[k]);
+                                c.id = id[k]; c.walked = (uint32_t)(cur[k] - home[k]) | (((walkm >> k) & 1u) ? kWalkOn : 0u);
                                 cand[at + rank[k]] = c;
                             }
                             at += cnt[k];
@@ -520,16 +497,18 @@ __global__ __launch_bounds__(256) void verify_kernel(
             if (act) r = cand[(uint64_t)c * kUChunk + k0 + lane];
             uint64_t quo;
             const uint64_t home = split_value(r.val, tab, &quo);
-            uint64_t s = home + r.walked;
+            uint64_t s = home + (r.walked & ~kWalkOn);
             bool found = false;
             Entry e;
             e.key = 0; e.oI = e.avg = e.fI = 0; e.wt = 0.f;
             if (act) {
-                e = load_entry(tab, s);
-                found = e.key == (int64_t)r.val;
-                if (!found) {                              // fingerprint collision: keep walking (KGJ:944-1034 semantics)
+                if (!(r.walked & kWalkOn)) {               // a fingerprint match at s: check the record
+                    e = load_entry(tab, s);
+                    found = e.key == (int64_t)r.val;
+                    if (!found) s += 1;                    // fingerprint collision: keep walking (KGJ:944-1034 semantics)
+                }
+                if (!found) {
                     const uint32_t f = tag_qs(quo, home);
-                    s += 1;
                     for (;;) {
                         if (s >= limit) { s = limit; break; }
                         const Tags16 x = load_tags(tab.tags + s);
@@ -671,17 +650,37 @@ __global__ __launch_bounds__(256) void place_unordered_kernel(const RowInfo *__r
     const unsigned long long cur = *cursor;
     if ((uint64_t)c >= (cur < ulist_cap ? cur : ulist_cap) / kUChunk) return;
     const uint32_t used = chunk_used[c];
-    for (uint32_t k = threadIdx.x; k < used; k += blockDim.x) {
-        kg_hit h = ulist[(uint64_t)c * kUChunk + k];
-        const uint32_t id = h.container;
-        const uint32_t it = id >> 9, r = (id >> 6) & 7u, ln = id & 63u;
-        const RowInfo ri = info[(uint64_t)it * ROWS + r];
-        // '+' rows ascend with the lane, '-' rows descend (see scan_kernel)
-        const unsigned long long before = ri.step < 0 ? (ln == 63 ? 0ull : (ri.mask >> (ln + 1))) : (ri.mask & ((1ull << ln) - 1ull));
-        h.container = ri.container;
-        h.from0InProt = ri.pos0 + ri.step * (int32_t)ln;
-        const uint64_t dst = (uint64_t)ri.off + (uint32_t)__popcll(before);
-        if (dst < hits_cap) hits[dst] = h;       // only out of range when a list overflowed: that scan is re-run
+    // kUChunk = 2 x 256: each thread places two records; both record loads, then both RowInfo loads, then the stores,
+    // so that a thread keeps two random lines in flight at every step
+    static_assert(kUChunk == 512, "place_unordered_kernel assumes two records per thread");
+    kg_hit h[2];
+    RowInfo ri[2];
+    bool act[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const uint32_t k = threadIdx.x + 256u * j;
+        act[j] = k < used;
+        if (act[j]) h[j] = ulist[(uint64_t)c * kUChunk + k];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if (act[j]) {
+            const uint32_t id = h[j].container;
+            ri[j] = info[(uint64_t)(id >> 9) * ROWS + ((id >> 6) & 7u)];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if (act[j]) {
+            const uint32_t ln = h[j].container & 63u;
+            // '+' rows ascend with the lane, '-' rows descend (see scan_kernel)
+            const unsigned long long before =
+                ri[j].step < 0 ? (ln == 63 ? 0ull : (ri[j].mask >> (ln + 1))) : (ri[j].mask & ((1ull << ln) - 1ull));
+            h[j].container = ri[j].container;
+            h[j].from0InProt = ri[j].pos0 + ri[j].step * (int32_t)ln;
+            const uint64_t dst = (uint64_t)ri[j].off + (uint32_t)__popcll(before);
+            if (dst < hits_cap) hits[dst] = h[j];       // only out of range when a list overflowed: that scan is re-run
+        }
     }
 }
 

@@ -99,8 +99,9 @@ struct DevCache {
 struct kg_table {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;      // partitioned scan: tag / verify passes of one chunk overlap the next chunk's scatter
-    hipEvent_t pev[18] = {};            // [2c] chunk c scattered, [2c+1] chunk c probed (c < 8); [16],[17] fork / join
+    hipStream_t stream2 = nullptr;      // partitioned scan: tag pass of chunk c while chunk c+1 is scattered (stream)
+    hipStream_t stream3 = nullptr;      // ... and while chunk c-1 is verified and placed
+    hipEvent_t pev[20] = {};            // [2c] chunk c scattered, [2c+1] chunk c tag-probed (c < 8); [16],[17],[18] fork / joins
     bool own_entries = false;
     uint8_t *d_entries = nullptr;
     uint8_t *d_tags = nullptr;
@@ -183,6 +184,7 @@ int table_finish(kg_table *t)
     for (auto &e : t->ev) HIP_TRY(hipEventCreate(&e));
     for (auto &e : t->pev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&t->stream3, hipStreamNonBlocking));
     return KG_OK;
 }
 
@@ -347,6 +349,7 @@ void kg_table_close(kg_table *t)
     for (auto &e : t->pev)
         if (e) (void)hipEventDestroy(e);
     if (t->stream2) { (void)hipStreamSynchronize(t->stream2); (void)hipStreamDestroy(t->stream2); }
+    if (t->stream3) { (void)hipStreamSynchronize(t->stream3); (void)hipStreamDestroy(t->stream3); }
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
 }
@@ -391,6 +394,7 @@ struct Scratch {
     {
         (void)hipStreamSynchronize(t->stream);      // blocks go back to the cache only when both streams are idle
         if (t->stream2) (void)hipStreamSynchronize(t->stream2);
+        if (t->stream3) (void)hipStreamSynchronize(t->stream3);
         for (void *p : ptrs) dfree(t, p);
     }
     void adopt(void *p) { ptrs.push_back(p); }
@@ -505,8 +509,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         constexpr uint32_t WIN = AA ? 64u : 384u;                                    // windows per block
         constexpr uint32_t kMaxChunks = 8;
         const uint32_t per_iter = kg::kScatterWaves;
-        // The batch is cut into chunks of whole sequences.  Chunk c goes through scatter (stream), then tag pass,
-        // verification and ordered placement (stream2) while chunk c+1 is scattered: the scatter pass is LDS/issue-
+        // The batch is cut into chunks of whole sequences.  Chunk c goes through scatter (stream), tag pass (stream2),
+        // then verification and ordered placement (stream3) while the chunks behind it are scattered and probed: the scatter pass is LDS/issue-
         // bound with one 16-wave workgroup per CU, the tag pass is L2-bound with few registers and no LDS, verification
         // and placement wait on random HBM lines, so they share the CUs.  A chunk's hits are a contiguous range of
         // hits[] (whole sequences), chained by a device-side running total.
@@ -558,12 +562,13 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
         const size_t lds = kg::scatter_lds_bytes<AA>(part_buckets);
         HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 4u) & ~7u;
+        const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 8u) & ~7u;
         const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
-        // per-chunk lists: hits (unordered) and candidates = fingerprint matches (hits + ~0.4 % of the probes)
+        // per-chunk lists: hits (unordered) and candidates = fingerprint matches (hits + ~0.4 % of the probes) + the
+        // ~2 % of the probes whose first tag window decides nothing
         const uint64_t list_slack = (uint64_t)(std::max(probe_grid, verify_grid) + 64) * 4 * kg::kUChunk + 4096;
         uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio * max_frac) + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
-        uint64_t ccap = ((uint64_t)((double)windows * (t->stage_ratio * 1.25 + 0.01) * max_frac) + list_slack + kg::kUChunk - 1) /
+        uint64_t ccap = ((uint64_t)((double)windows * (t->stage_ratio * 1.25 + 0.03) * max_frac) + list_slack + kg::kUChunk - 1) /
                         kg::kUChunk * kg::kUChunk;
         kg_hit *d_ulist = nullptr;
         uint32_t *d_cused = nullptr, *d_candused = nullptr;
@@ -589,6 +594,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
             HIP_TRY(hipMemsetAsync(d_masks, 0, n_rows * 8, t->stream));
             HIP_TRY(hipEventRecord(t->pev[16], t->stream));               // fork: stream2 starts behind the clears
             HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[16], 0));
+            HIP_TRY(hipStreamWaitEvent(t->stream3, t->pev[16], 0));
 #define KG_PROBE_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic
             for (uint32_t c = 0; c < n_chunks_p; c++) {
                 const uint32_t lo = (uint32_t)clo[c], nb = (uint32_t)(clo[c + 1] - clo[c]);
@@ -607,21 +613,23 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                                    cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, d_ctr);
                 HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
                 HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
-                hipStream_t s2 = t->stream2;
+                hipStream_t s2 = t->stream2, s3 = t->stream3;
 #define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
                     candused_c, ccur_c, ccap, d_ctr
 #define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_masks, d_ctr
+                if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
+                else hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
+                HIP_TRY(hipEventRecord(t->pev[2 * c + 1], s2));
+                HIP_TRY(hipStreamWaitEvent(s3, t->pev[2 * c + 1], 0));
                 if (counters) {
-                    hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
-                    hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, s2, KG_PROBE_ARGS, cand_c,
+                    hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, s3, KG_PROBE_ARGS, cand_c,
                                        candused_c, ccur_c, ccap, KG_ULIST_ARGS);
-                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(64), dim3(256), 0, s2, KG_PROBE_ARGS,
+                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(64), dim3(256), 0, s3, KG_PROBE_ARGS,
                                        ovf_bucket_c, ovf_ent_c, ovfc_c, ovf_cap, part_shift, KG_ULIST_ARGS);
                 } else {
-                    hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
-                    hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, s2, KG_PROBE_ARGS, cand_c,
+                    hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, s3, KG_PROBE_ARGS, cand_c,
                                        candused_c, ccur_c, ccap, KG_ULIST_ARGS);
-                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(64), dim3(256), 0, s2, KG_PROBE_ARGS,
+                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(64), dim3(256), 0, s3, KG_PROBE_ARGS,
                                        ovf_bucket_c, ovf_ent_c, ovfc_c, ovf_cap, part_shift, KG_ULIST_ARGS);
                 }
 #undef KG_TAG_ARGS
@@ -629,13 +637,13 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                 // ordered placement of the chunk's hits
                 const uint64_t rows_c = (uint64_t)nb * PER, row_lo = (uint64_t)lo * PER;
                 const uint32_t rgrid = (uint32_t)((rows_c + 255) / 256);
-                hipLaunchKernelGGL((kg::rows_from_masks_kernel<AA>), dim3(rgrid), dim3(256), 0, s2, d_blocks, lo, nb, d_masks, d_counts);
-                if ((rc = prefix_sum(t, d_counts + row_lo, rows_c, d_offs + row_lo, d_partial_c + c * partial_stride, ctot_c, s2))) return rc;
-                hipLaunchKernelGGL(kg::chunk_base_kernel, dim3(1), dim3(1), 0, s2, ctot_c, base_c,
+                hipLaunchKernelGGL((kg::rows_from_masks_kernel<AA>), dim3(rgrid), dim3(256), 0, s3, d_blocks, lo, nb, d_masks, d_counts);
+                if ((rc = prefix_sum(t, d_counts + row_lo, rows_c, d_offs + row_lo, d_partial_c + c * partial_stride, ctot_c, s3))) return rc;
+                hipLaunchKernelGGL(kg::chunk_base_kernel, dim3(1), dim3(1), 0, s3, ctot_c, base_c,
                                    c + 1 == n_chunks_p ? d_totals : (uint64_t *)nullptr);
-                hipLaunchKernelGGL((kg::row_info_kernel<AA>), dim3(rgrid), dim3(256), 0, s2, d_blocks, lo, nb, d_masks, d_offs, base_c,
+                hipLaunchKernelGGL((kg::row_info_kernel<AA>), dim3(rgrid), dim3(256), 0, s3, d_blocks, lo, nb, d_masks, d_offs, base_c,
                                    d_info);
-                hipLaunchKernelGGL((kg::place_unordered_kernel<AA>), dim3((uint32_t)(ucap / kg::kUChunk)), dim3(256), 0, s2, d_info,
+                hipLaunchKernelGGL((kg::place_unordered_kernel<AA>), dim3((uint32_t)(ucap / kg::kUChunk)), dim3(256), 0, s3, d_info,
                                    ulist_c, cused_c, ucur_c, ucap, res->d_hits, hits_cap);
                 HIP_TRY(hipGetLastError());
                 if (c + 1 == n_chunks_p) HIP_TRY(hipEventRecord(t->ev[5], t->stream));   // all chunks scattered
@@ -643,6 +651,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
 #undef KG_PROBE_ARGS
             HIP_TRY(hipEventRecord(t->pev[17], t->stream2));              // join
             HIP_TRY(hipStreamWaitEvent(t->stream, t->pev[17], 0));
+            HIP_TRY(hipEventRecord(t->pev[18], t->stream3));
+            HIP_TRY(hipStreamWaitEvent(t->stream, t->pev[18], 0));
             HIP_TRY(hipEventRecord(t->ev[7], t->stream));
             st.scan_launches++;
             uint64_t h_pc[48];
