@@ -487,12 +487,13 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
     {
         // bucket = 2^shift slots (= bytes of tags); at most kMaxBuckets buckets; quotient must fit 32 - shift bits
         uint32_t shift = env_u32("KG_PART_SHIFT", 21u);
+        const uint64_t qmax = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1;
+        while (shift > 4 && qmax >= (1ull << (32 - shift))) shift--;     // small tables: large quotients, small buckets
         while (((t->limit + (1ull << shift) - 1) >> shift) > (uint64_t)kg::kMaxBuckets) shift++;
         // the scatter workgroup keeps a 128-byte buffer per bucket in LDS: at most 160 KiB with its encode scratch
         while (AA ? kg::scatter_lds_bytes<true>((uint32_t)((t->limit + (1ull << shift) - 1) >> shift)) > 160u * 1024
                   : kg::scatter_lds_bytes<false>((uint32_t)((t->limit + (1ull << shift) - 1) >> shift)) > 160u * 1024)
             shift++;
-        const uint64_t qmax = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1;
         // the scatter pass splits k-mers with kg::split_fast: 64 <= numSigs < 2^31
         const bool fits = shift < 32 && qmax < (1ull << (32 - shift)) && nblocks <= (1ull << 23) && t->m35 != 0;
         // Measured at 1 Gbp x 33.6 GB table (profiles/r01_partition_path.md): direct 31.9 ms; partitioned 27.1 ms
@@ -517,7 +518,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         uint32_t want = env_u32("KG_PART_CHUNKS", 4u);
         if (want < 1) want = 1;
         if (want > kMaxChunks) want = kMaxChunks;
-        while (want > 1 && nblocks / want < 64ull * 1024) want--;
+        const uint64_t min_chunk = std::max(1u, env_u32("KG_PART_MIN_CHUNK_BLOCKS", 64u * 1024u));   // tests lower it
+        while (want > 1 && nblocks / want < min_chunk) want--;
         std::vector<uint64_t> clo;                                                    // chunk c = blocks [clo[c], clo[c+1])
         clo.push_back(0);
         for (uint32_t c = 1; c < want; c++) {
@@ -539,7 +541,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         const uint32_t cap = (uint32_t)(((uint64_t)(mean + 6.0 * std::sqrt(mean) + 32.0) + 15) / 16 * 16);
         const uint64_t n_regions_total = (uint64_t)part_buckets * n_wg;               // per chunk
         // overflow list of one chunk (groups)
-        const uint32_t ovf_cap = env_u32("KG_PART_OVF_GROUPS", (uint32_t)std::min<uint64_t>(1u << 21, std::max<uint64_t>(4096, n_regions_total * cap / 16 / 64)));
+        const uint32_t ovf_cap = env_u32("KG_PART_OVF_GROUPS", (uint32_t)std::min<uint64_t>(1u << 21, std::max<uint64_t>(65536, n_regions_total * cap / 16 / 64)));
         uint64_t *d_ent = nullptr, *d_ovf_ent = nullptr;
         uint32_t *d_fill = nullptr, *d_ovf_bucket = nullptr, *d_next = nullptr, *d_ovfc = nullptr;
         unsigned long long *d_masks = nullptr;

@@ -24,20 +24,22 @@ def assert_same_records(gpu, ora, what=""):
     mode = os.environ.get("KG_PARTITION")
     if mode == "0":
         assert gpu.stats["partitioned"] == 0, what + ": direct strategy requested"
-    if mode == "1" and gpu.stats["n_blocks"] > 0 and os.environ.get("KG_PART_OVF_GROUPS") is None and _partition_fits(gpu.stats):
+    if mode == "1" and gpu.stats["n_blocks"] > 0 and os.environ.get("KG_PART_OVF_GROUPS") is None and os.environ.get("KG_PART_SLACK") is None and _partition_fits(gpu.stats):
         assert gpu.stats["partitioned"] == 1, what + ": the partitioned strategy fell back to direct probing"
 
 
 def _partition_fits(stats) -> bool:
     """The library's own eligibility rule for the partitioned strategy (kmerguts_hip.hip, scan_impl)."""
     num_sigs = stats["table_bytes"] // 24
+    qmax = 20 ** 8 // num_sigs + 1
     shift = 21
+    while shift > 4 and qmax >= (1 << (32 - shift)):
+        shift -= 1
     while ((num_sigs + (1 << shift) - 1) >> shift) > 1024:
         shift += 1
     enc = 3632 * 16 + 1280 if stats["n_containers"] != stats["n_seqs"] else 640 * 16 + 1024   # WaveLds<AA> x 16 + tables
     while enc + ((num_sigs + (1 << shift) - 1) >> shift) * 140 > 160 * 1024:
         shift += 1
-    qmax = 20 ** 8 // num_sigs + 1
     return shift < 32 and qmax < (1 << (32 - shift)) and stats["n_blocks"] <= (1 << 23) and 64 <= num_sigs < (1 << 31)
 
 

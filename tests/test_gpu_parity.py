@@ -375,3 +375,47 @@ def test_skewed_repeats_overflow_and_fallback(hp, oracle, monkeypatch, strategy)
                 assert_same_records(r, ora, "skew %s %s" % (strategy, env))
                 assert r.stats["windows_valid"] == ora["windows_valid"]
                 assert r.stats["slots_inspected"] == ora["slots_inspected"]
+
+
+def test_partitioned_chunk_pipeline(hp, oracle, monkeypatch):
+    """The partitioned strategy cuts a batch into chunks of whole sequences and chains their hit ranges on the
+    device.  Force up to 8 chunks on small batches: ragged lengths, empty and too-short sequences at the cuts, one
+    sequence much longer than a chunk, DNA and protein; -O and a small gap so that CALLs cross block borders."""
+    from kmergutsjava_amd import synth
+    monkeypatch.setenv("KG_PARTITION", "1")
+    monkeypatch.setenv("KG_PART_MIN_CHUNK_BLOCKS", "1")
+    keys = synth.random_keys(500_000, 77)
+    rec, placed = synth.build_table(keys, synth.payload_of(keys, 76, n_otu=5, n_fn=7), 1_000_003)
+    img = _img(rec)
+    # DNA: 40 ragged contigs + empties + one long contig in the middle
+    lens = [0, 5, 23, 24, 300, 0, 7000, 191, 192, 193, 40000, 0, 0, 815, 100000] + [1000 + 37 * i for i in range(25)] + [0, 23]
+    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    seq = synth.random_dna(int(off[-1]), 78)
+    sb = plant(seq.numpy().tobytes(), off, keys.tolist(), every=53)
+    n_calls = 0
+    for chunks in (2, 3, 5, 8):
+        monkeypatch.setenv("KG_PART_CHUNKS", str(chunks))
+        for oc, mh, gap in ((False, 2, 200), (True, 2, 30)):
+            ora = oracle.run(img, sb, off, order_constraint=oc, min_hits=mh, max_gap=gap, lookup_mode=1)
+            n_calls = max(n_calls, len(ora["calls"]))
+            with hp.SignatureTable.from_bytes(img) as tab:
+                with tab.scan(sb, off, hp.Params(order_constraint=oc, min_hits=mh, max_gap=gap, counters=True)) as r:
+                    assert r.stats["partitioned"] == 1
+                    assert_same_records(r, ora, "dna chunks=%d oc=%s" % (chunks, oc))
+                    assert r.stats["slots_inspected"] == ora["slots_inspected"]
+        assert len(ora["hits"]) > 1000 and n_calls > 10
+    # protein
+    plens = [0, 8, 9, 64, 65, 500, 0, 3000] + [100 + 13 * i for i in range(30)] + [7]
+    poff = np.zeros(len(plens) + 1, dtype=np.int64)
+    np.cumsum(plens, out=poff[1:])
+    pseq = synth.random_protein(int(poff[-1]), 79)
+    psb = plant(pseq.numpy().tobytes(), poff, keys.tolist(), every=29, dna=False)
+    ora = oracle.run(img, psb, poff, aa=True, min_hits=2, lookup_mode=1)
+    assert len(ora["hits"]) > 100
+    for chunks in (2, 4, 7):
+        monkeypatch.setenv("KG_PART_CHUNKS", str(chunks))
+        with hp.SignatureTable.from_bytes(img) as tab:
+            with tab.scan(psb, poff, hp.Params(aa=True, min_hits=2)) as r:
+                assert r.stats["partitioned"] == 1
+                assert_same_records(r, ora, "aa chunks=%d" % chunks)
