@@ -170,8 +170,8 @@ def main():
                        "parallelism": "contig shards x%d, table replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("scan stage = kg::part_scatter_kernel || kg::bucket_tag_kernel (4 chunks, two streams) + "
-                                    "kg::verify_kernel" if partitioned else "kg::scan_kernel<false,false,3>"),
+                         "kernel": ("scan stage = kg::part_scatter_kernel || kg::bucket_tag_kernel || kg::verify_kernel + "
+                                    "kg::place_unordered_kernel (chunks of whole contigs on three streams)" if partitioned else "kg::scan_kernel<false,false,3>"),
                          "kernel_ms": ms_scan,
                          "passes_ms": ({k: float(np.mean(v)) for k, v in pass_ms.items()} if partitioned else None),
                          "strategy": "partitioned" if partitioned else "direct",
@@ -181,7 +181,7 @@ def main():
                          "device_total": float(np.mean(total_ms))},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, rec, seq, off)
+            out["cpu_baseline"] = cpu_baseline(args, rec, seq, off, tab)
         print(json.dumps(out), flush=True)
 
     tab.close()
@@ -189,9 +189,10 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, rec, seq, off):
+def cpu_baseline(args, rec, seq, off, tab):
     """The C restatement of the reference algorithm (oracle/, literal sorted merge-join, 1 thread)
-    timed on the first contigs of the same workload against the same table."""
+    timed on the first contigs of the same workload against the same table.  Its records are also the checker
+    for the full-size GPU scan: the hit / CALL / OTU records of these contigs must be byte-identical."""
     import struct
     from oracle import kgo
     kgo.build()
@@ -210,7 +211,19 @@ def cpu_baseline(args, rec, seq, off):
     phases = o["t_prepare"] + o["t_lookup"] + o["t_group"]
     log("[bench] cpu_baseline: %d residues in %.1f s (prepare %.1f, lookup %.1f, group %.1f)" %
         (o["residues"], wall, o["t_prepare"], o["t_lookup"], o["t_group"]))
-    return {"value": o["residues"] / phases, "unit": "residues/s", "cores": 1, "kind": "port",
+    # parity of the full-size scan (all chunks, same strategy as the timed steps) on the sample's containers
+    from kmergutsjava_amd import hotpath
+    with tab.scan(None, off, hotpath.Params(), device_ptr=seq.data_ptr()) as r:
+        chs, ccs = r.container_hit_start(), r.container_call_start()
+        nc = n * 6
+        g_hits, g_calls, g_otu = r.hits()[:int(chs[nc])], r.calls()[:int(ccs[nc])], r.otu()[:n]
+        same = (g_hits.tobytes() == o["hits"].tobytes() and g_calls.tobytes() == o["calls"].tobytes() and
+                g_otu.tobytes() == o["otu"].tobytes() and np.array_equal(chs[:nc + 1], o["container_hit_start"]))
+        parity = {"contigs": n, "hits": int(len(o["hits"])), "calls": int(len(o["calls"])), "identical": bool(same),
+                  "strategy": "partitioned" if r.stats["partitioned"] else "direct"}
+    log("[bench] parity of the full-size scan on the sample: %s" % parity)
+    assert same, "full-size GPU scan differs from the oracle on the sample contigs"
+    return {"value": o["residues"] / phases, "unit": "residues/s", "cores": 1, "kind": "port", "parity_sample": parity,
             "sample": "first %d contigs (%d bp, %d residues, %d query k-mers: one <=20 M-k-mer batch) of the same "
                       "contig mix against the same table; C restatement of the reference's materialise -> sort by "
                       "(value %% numSigs, value) -> streamed merge-join -> gatherHits, single thread"
