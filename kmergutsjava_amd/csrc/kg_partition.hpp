@@ -2,7 +2,8 @@
 //
 // Why: a probe is a random 16-byte read; from a table far larger than the 4 MiB L2 of an XCD every probe
 // costs a whole 128-byte line from the memory side and the chip tops out at ~50 G such reads per second
-// (profiles/r01_gather_ceiling*.jsonl), while L2-resident random reads run at 220-270 G/s.  So the query
+// (profiles/r01_gather_ceiling*.jsonl), while L2-resident random reads run at 220-270 G/s (one 64-byte sector
+// fill each: the XCD-resident gather bandwidth of MI355X_MICROARCH.md).  So the query
 // k-mers are first bucketed by slot range (a bucket's tag range <= 2 MiB), then probed bucket by bucket with
 // all the workgroups of one XCD working on the same bucket.  The reference does the same thing for the same
 // reason with a sort and a sequential merge (KGJ:1076-1095, 944-1034); here it is one scatter pass (8 bytes
@@ -10,18 +11,20 @@
 //
 //   part_scatter_kernel  : encode every window once; entry -> 16-entry (128-byte) write-combining buffer of its
 //                          bucket in the workgroup's LDS -> the workgroup's over-allocated region of the bucket
-//                          (no counting pass, no per-entry global atomics; overflow list for skewed inputs)
+//                          (no counting pass, no per-entry global atomics, no workgroup barrier in the main loop;
+//                          overflow list for skewed inputs)
 //   bucket_tag_kernel    : persistent workgroups; group x = blockIdx % 8 (XCD under round-robin placement,
-//                          speed only) walks the buckets b % 8 == x; per entry a 16-tag walk out of L2; a
-//                          fingerprint match becomes a 16-byte candidate record
-//   verify_kernel        : one lane per candidate: fetch the 24-byte record, compare the key; a hit sets bit
-//                          `lane` in the 64-bit mask of its (block,row) and appends {id, payload} to an
-//                          unordered list
+//                          speed only) walks the buckets b % 8 == x; per entry one 16-tag window out of L2: an
+//                          empty slot ends it, a fingerprint match or an undecided window becomes a 16-byte
+//                          candidate record
+//   verify_kernel        : one lane per candidate: (continue the tag walk,) fetch the 24-byte record, compare the
+//                          key; a hit sets bit `lane` in the 64-bit mask of its (block,row) and appends
+//                          {id, payload} to an unordered list
 //   overflow_probe_kernel: the groups the scatter pass could not fit into their regions
-//   rows_from_masks      : popcount of the masks -> counts[] in container-major row order (then the usual
-//                          prefix sum)
+//   rows_from_masks      : popcount of the masks -> counts[] in container-major row order (then a prefix sum)
 //   row_info / place_unordered : unordered list -> hits[] at off[row] + popcount(mask bits before the lane)
-// The batch is processed in chunks of blocks: scatter of chunk c+1 overlaps the tag pass of chunk c (two streams).
+// The batch is processed in chunks of whole sequences; scatter, tag pass and verification + placement of successive
+// chunks run on three streams (kmerguts_hip.hip, scan_impl).
 //
 // Entry (64 bit): low word = quotient << shift | slot_low, high word = id = block << 9 | row << 6 | lane;
 // value = quotient * numSigs + (bucket << shift | slot_low) exactly.
@@ -167,11 +170,6 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 if (valid) pend |= 1u << r;
             }
             wave_sync();   // the wave's encode scratch is reused by its next block
-#if defined(KG_ABLATE) && KG_ABLATE == 1    // tuning builds only: encode + split, no insertion (results are wrong)
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) if (pend & (1u << r)) n_valid += e[r] ^ bk[r];
-            pend = 0;
-#endif
         }
         // Insert without workgroup barriers.  A bucket's buffer is a 16-entry group with two counters:
         //   cnt[b]      tickets: atomicAdd gives the entry's place; >= 16 means "full, try again"
@@ -210,6 +208,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 for (int r = 1; r < ROWS; r++)
                     if (r0 == r) b = bk[r];
                 unsigned long long dst_off = ~0ull;                    // entry index in ent (bit 62: in ovf_ent)
+                bool to_ovf = false;
                 if (has) {
                     done &= done - 1;
                     const uint32_t rel = wrel[b];
@@ -217,7 +216,16 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                         dst_off = ((uint64_t)b * n_wg + w) * cap + rel;
                         wrel[b] = rel + kGroup;
                     } else {
-                        const uint32_t g = atomicAdd(ovf_cursor, 1u);
+                        to_ovf = true;
+                    }
+                }
+                const unsigned long long movf = __ballot(to_ovf);      // region full: overflow list, one atomic per pass
+                if (movf) {
+                    uint32_t g0 = 0;
+                    if (lane == 0) g0 = atomicAdd(ovf_cursor, (uint32_t)__popcll(movf));
+                    g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0);
+                    if (to_ovf) {
+                        const uint32_t g = g0 + (uint32_t)__popcll(movf & ((1ull << lane) - 1ull));
                         if (g < ovf_cap) { ovf_bucket[g] = b; dst_off = (1ull << 62) | ((uint64_t)g * kGroup); }
                         else dst_off = ~0ull - 1;                     // dropped (the host falls back to direct probing)
                     }
@@ -247,7 +255,10 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 if (has) { written[b] = 0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); cnt[b] = 0; }
             }
             if (!__ballot(pend != 0)) break;
-            if (++spins > (1u << 18)) {                                // never expected; see above
+            // entries left: their buffers were full.  Back off before trying again, or the retries of 16 waves on one
+            // counter (heavily repeated k-mers) keep the LDS busy and starve the wave that is flushing.
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 20)) {                                // never expected; see above
                 if (lane == 0) atomicAdd(ovf_cursor, ovf_cap + 1u);
                 break;
             }

@@ -496,9 +496,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
             shift++;
         // the scatter pass splits k-mers with kg::split_fast: 64 <= numSigs < 2^31
         const bool fits = shift < 32 && qmax < (1ull << (32 - shift)) && nblocks <= (1ull << 23) && t->m35 != 0;
-        // Measured at 1 Gbp x 33.6 GB table (profiles/r01_partition_path.md): direct 31.9 ms; partitioned 27.1 ms
-        // (scatter 13.9 + tag 10.8 + verify 2.5) with 5x less DRAM traffic.  Small inputs and L2/MALL-sized tables
-        // stay on the direct kernel.  KG_PARTITION: 0 direct, 1 partitioned whenever possible, 2 (default) auto.
+        // Measured against the 33.6 GB table (profiles/r01_partition_path.md), whole scan incl. ordering, direct vs
+        // partitioned: 1 Gbp 35.0 / 21.4 ms, 600 Mbp 21.8 / 13.6, 400 Mbp 14.6 / 9.4, 200 Mbp 7.0 / 5.4, 100 Mbp 3.6 / 3.4 (one chunk).
+        // Small inputs and L2/MALL-sized tables stay on the direct kernel.
+        // KG_PARTITION: 0 direct, 1 partitioned whenever possible, 2 (default) auto.
         const uint32_t mode = env_u32("KG_PARTITION", 2u);
         const bool worth = t->limit >= (64ull << 20) && windows >= (1ull << 27);
         use_part = fits && nblocks > 0 && (mode == 1 || (mode == 2 && worth));
@@ -518,7 +519,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         uint32_t want = env_u32("KG_PART_CHUNKS", 4u);
         if (want < 1) want = 1;
         if (want > kMaxChunks) want = kMaxChunks;
-        const uint64_t min_chunk = std::max(1u, env_u32("KG_PART_MIN_CHUNK_BLOCKS", 64u * 1024u));   // tests lower it
+        const uint64_t min_chunk = std::max(1u, env_u32("KG_PART_MIN_CHUNK_BLOCKS", 1u << 20));   // ~200 Mbp; tests lower it
         while (want > 1 && nblocks / want < min_chunk) want--;
         std::vector<uint64_t> clo;                                                    // chunk c = blocks [clo[c], clo[c+1])
         clo.push_back(0);

@@ -21,7 +21,7 @@ def timed(tab, off, params, seq_dev, reps=4):
             best = (w, st)
     w, st = best
     return {"ms_per_step": w * 1e3, "residues_per_s": st["residues"] / w, "hits_per_s": st["n_hits"] / w,
-            "calls_per_s": st["n_calls"] / w, "n_hits": st["n_hits"], "n_calls": st["n_calls"], "residues": st["residues"],
+            "calls_per_s": st["n_calls"] / w, "partitioned": st["partitioned"], "n_hits": st["n_hits"], "n_calls": st["n_calls"], "residues": st["residues"],
             "stage_ms": {k: st[k] for k in ("ms_scan", "ms_order", "ms_aggregate", "ms_total")}}
 
 def check(tab, img, seq_dev, off, n_seqs, **kw):
