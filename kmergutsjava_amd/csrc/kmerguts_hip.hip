@@ -573,6 +573,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio * max_frac) + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         uint64_t ccap = ((uint64_t)((double)windows * (t->stage_ratio * 1.25 + 0.03) * max_frac) + list_slack + kg::kUChunk - 1) /
                         kg::kUChunk * kg::kUChunk;
+        if (env_u32("KG_TEST_TINY_LISTS", 0u)) ucap = ccap = kg::kUChunk;      // tests: force the resize-and-rerun path
         kg_hit *d_ulist = nullptr;
         uint32_t *d_cused = nullptr, *d_candused = nullptr;
         kg::CandRec *d_cand = nullptr;
@@ -683,8 +684,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
             dfree(t, d_ulist); dfree(t, d_cused); dfree(t, d_cand); dfree(t, d_candused); dfree(t, res->d_hits);   // both streams are idle
             d_ulist = nullptr; d_cused = nullptr; d_cand = nullptr; d_candused = nullptr; res->d_hits = nullptr;
             if (attempt == 2) return fail(KG_ERR_DEVICE, "hit list overflow after resize (internal error)");
-            if (need_c > ccap) { ccap = (need_c + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk; ucap = std::max(ucap, ccap); }   // hits <= candidates
-            else ucap = (need_u + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
+            // which wave fills which reservation chunk differs from run to run: one partly used chunk per wave on top
+            if (need_c > ccap) { ccap = (need_c + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk; ucap = std::max(ucap, ccap); }   // hits <= candidates
+            else ucap = (need_u + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         }
         sc.adopt(d_cand); sc.adopt(d_candused);
         sc.adopt(d_ulist); sc.adopt(d_cused);
@@ -719,6 +721,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
     uint64_t stage_cap = (uint64_t)((double)windows * t->stage_ratio) + 4096 +
                          (uint64_t)scan_grid * kg::kWavesPerWG * stage_chunk;
     if (stage_cap > 0xFFFFFF00ull) stage_cap = 0xFFFFFF00ull;
+    if (env_u32("KG_TEST_TINY_LISTS", 0u)) stage_cap = 256;                    // tests: force the resize-and-rerun path
     kg_hit *d_stage = nullptr;
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = dalloc(t, (void **)&d_stage, stage_cap * sizeof(kg_hit)))) return rc;

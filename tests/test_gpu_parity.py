@@ -419,3 +419,26 @@ def test_partitioned_chunk_pipeline(hp, oracle, monkeypatch):
             with tab.scan(psb, poff, hp.Params(aa=True, min_hits=2)) as r:
                 assert r.stats["partitioned"] == 1
                 assert_same_records(r, ora, "aa chunks=%d" % chunks)
+
+
+def test_list_resize_and_rerun(hp, oracle, monkeypatch, strategy):
+    """The hit / candidate lists (partitioned) and the staging area (direct) are sized from the hit rate seen so far;
+    when they are too small the scan is re-run once with the exact size.  Force that path."""
+    from kmergutsjava_amd import synth
+    seq, off, rec, keys = synth.high_density_config(12, 150, 200003, 5000, seed=91, dna=True)
+    img = _img(rec)
+    sb = seq.numpy().tobytes()
+    ora = oracle.run(img, sb, off, min_hits=3, lookup_mode=1)
+    assert len(ora["hits"]) > 1000 and len(ora["calls"]) > 50
+    monkeypatch.setenv("KG_PART_MIN_CHUNK_BLOCKS", "1")
+    monkeypatch.setenv("KG_PART_CHUNKS", "3")
+    with hp.SignatureTable.from_bytes(img) as tab:
+        monkeypatch.setenv("KG_TEST_TINY_LISTS", "1")
+        with tab.scan(sb, off, hp.Params(min_hits=3, counters=True)) as r:
+            assert r.stats["scan_launches"] == 2, r.stats["scan_launches"]
+            assert_same_records(r, ora, "resized " + strategy)
+            assert r.stats["slots_inspected"] == ora["slots_inspected"] and r.stats["windows_valid"] == ora["windows_valid"]
+        monkeypatch.delenv("KG_TEST_TINY_LISTS")
+        with tab.scan(sb, off, hp.Params(min_hits=3)) as r:              # the table remembers the hit rate: one launch
+            assert r.stats["scan_launches"] == 1
+            assert_same_records(r, ora, "after resize " + strategy)
