@@ -230,21 +230,19 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                         else dst_off = ~0ull - 1;                     // dropped (the host falls back to direct probing)
                     }
                 }
-                while (m) {
-                    // the next (up to) eight flushing lanes; lane group g = lane / 8 takes the g-th of them
-                    int src_lane = -1;
-                    unsigned long long mm = m;
-#pragma unroll
-                    for (int g = 0; g < 8; g++) {
-                        const int ln = mm ? __builtin_ctzll(mm) : -1;
-                        if (mm) mm &= mm - 1;
-                        if ((lane >> 3) == g) src_lane = ln;
-                    }
-                    m = mm;
-                    const int sl = src_lane < 0 ? 0 : src_lane;
+                // eight lanes copy one group; lane group g = lane / 8 serves the flushing lane of rank g + 8 * pass.
+                // rank -> lane goes through 64 bytes of the wave's (idle) encode scratch instead of a scalar bit loop
+                uint8_t *rank_lane = reinterpret_cast<uint8_t *>(&l);
+                const uint32_t n_flush = (uint32_t)__popcll(m);
+                if (has) rank_lane[__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+                wave_sync();
+                for (uint32_t p0 = 0; p0 < n_flush; p0 += 8) {
+                    const uint32_t want = p0 + ((uint32_t)lane >> 3);
+                    const bool serve = want < n_flush;
+                    const int sl = serve ? (int)rank_lane[want] : 0;
                     const uint32_t fb = (uint32_t)__shfl((int)b, sl);
                     const unsigned long long off = __shfl(dst_off, sl);
-                    if (src_lane >= 0 && off != ~0ull - 1) {
+                    if (serve && off != ~0ull - 1) {
                         const uint32_t sub = (uint32_t)lane & 7u;
                         const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(buf + (size_t)fb * kGroup + 2 * sub);
                         uint64_t *base = (off >> 62) & 1 ? ovf_ent + (off & ~(1ull << 62)) : ent + off;
