@@ -94,6 +94,56 @@ struct DevCache {
     }
 };
 
+// Pinned host blocks for the result views (hipHostMalloc / hipHostFree cost ~0.1-0.2 ms each: more than a small
+// scan).  Only blocks up to 64 MiB are kept.
+struct PinCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_;
+    std::unordered_map<void *, size_t> live;
+    static constexpr size_t kKeepMax = 64u << 20;
+
+    hipError_t get(void **p, size_t bytes)
+    {
+        bytes = bytes < 4096 ? 4096 : (bytes + 4095) / 4096 * 4096;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_.lower_bound(bytes);
+            if (it != free_.end() && it->first <= 2 * bytes + (1u << 16)) {
+                *p = it->second;
+                live[*p] = it->first;
+                free_.erase(it);
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipHostMalloc(p, bytes);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lk(mu);
+        live[*p] = bytes;
+        return hipSuccess;
+    }
+    void put(void *p)
+    {
+        size_t bytes = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = live.find(p);
+            if (it == live.end()) return;
+            bytes = it->second;
+            live.erase(it);
+            if (bytes <= kKeepMax) { free_.emplace(bytes, p); return; }
+        }
+        (void)hipHostFree(p);
+    }
+    void release_all()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &kv : free_) (void)hipHostFree(kv.second);
+        for (auto &kv : live) (void)hipHostFree(kv.first);
+        free_.clear();
+        live.clear();
+    }
+};
+
 }  // namespace
 
 struct kg_table {
@@ -113,6 +163,7 @@ struct kg_table {
     double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
     hipEvent_t ev[8] = {};
     DevCache cache;
+    PinCache pins;
 };
 
 struct kg_result {
@@ -344,6 +395,7 @@ void kg_table_close(kg_table *t)
     if (t->own_entries && t->d_entries) (void)hipFree(t->d_entries);
     if (t->d_tags) (void)hipFree(t->d_tags);
     t->cache.release_all();
+    t->pins.release_all();
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : t->pev)
@@ -364,7 +416,7 @@ void kg_result_free(kg_result *r)
         dfree(t, r->d_ev); dfree(t, r->d_tail_ev);
     }
     for (void *h : {r->h_hits, r->h_chs, r->h_ccs, r->h_calls, r->h_otu, r->h_ev, r->h_tail_ev})
-        if (h) (void)hipHostFree(h);
+        if (h) { if (t) t->pins.put(h); else (void)hipHostFree(h); }
     delete r;
 }
 
@@ -892,9 +944,9 @@ const T *host_view(kg_result *r, void *&slot, const T *d, size_t n)
     if (!d && n) { g_err = "record kind not computed (KG_F_SKIP_AGGREGATE?)"; return nullptr; }
     if (hipSetDevice(r->tab->device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
     void *h = nullptr;
-    if (hipHostMalloc(&h, n ? n * sizeof(T) : 64) != hipSuccess) { g_err = "pinned host allocation failed"; return nullptr; }
+    if (r->tab->pins.get(&h, n ? n * sizeof(T) : 64) != hipSuccess) { g_err = "pinned host allocation failed"; return nullptr; }
     if (n && hipMemcpy(h, d, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) {
-        (void)hipHostFree(h);
+        r->tab->pins.put(h);
         g_err = "device to host copy failed";
         return nullptr;
     }
