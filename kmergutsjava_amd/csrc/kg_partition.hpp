@@ -178,14 +178,19 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
         //               then cnt = 0).  Nobody else touches buf[b] / wrel[b] between the 16th ticket and the reopening.
         // LDS operations of one wave execute in program order and LDS is coherent in the workgroup, so the fences
         // below only pin the compiler's order.  A lane that keeps failing waits for a flush that the owning wave
-        // performs right after its own stores; the spin guard turns a protocol bug into the host's fallback to the
-        // direct strategy (overflow > cap) instead of a hang.
+        // performs right after its own stores; it polls the counter with plain reads in the meantime: retrying the
+        // atomic instead (16 waves on one counter: homopolymer runs) starves the flushing wave and can run the
+        // 32-bit ticket counter round to zero, which hands out a full buffer's slots again (seen as an intermittent
+        // stall before the polling loop existed).  The guards turn any remaining protocol failure into the host's
+        // fallback to the direct strategy (overflow > cap) instead of a hang or a wrong result.
         uint32_t done = 0, spins = 0;
         for (;;) {
             uint32_t at[ROWS];
 #pragma unroll
             for (int r = 0; r < ROWS; r++)                             // the LDS atomics of all rows in flight together
                 at[r] = (pend & (1u << r)) ? atomicAdd(&cnt[bk[r]], 1u) : kGroup;
+            // (retry rounds look before they draw: a full buffer is polled with plain reads, so that waiting lanes
+            //  neither serialise on the counter against the flushing wave nor run the counter round to zero)
 #pragma unroll
             for (int r = 0; r < ROWS; r++)
                 if (at[r] < kGroup) buf[(size_t)bk[r] * kGroup + at[r]] = e[r];
@@ -253,10 +258,21 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 if (has) { written[b] = 0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); cnt[b] = 0; }
             }
             if (!__ballot(pend != 0)) break;
-            // entries left: their buffers were full.  Back off before trying again, or the retries of 16 waves on one
-            // counter (heavily repeated k-mers) keep the LDS busy and starve the wave that is flushing.
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 20)) {                                // never expected; see above
+            // entries left: their buffers were full.  Wait until one of them reopens (bounded), then try again.
+            for (uint32_t polls = 0; polls < 64; polls++) {
+                bool open = false;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++)
+                    if (pend & (1u << r)) open = open || *const_cast<volatile uint32_t *>(&cnt[bk[r]]) < kGroup;
+                if (__ballot(open)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            // Never expected (see above).  The second test keeps a ticket counter far from wrapping round to zero,
+            // which would hand out the slots of a full buffer a second time.
+            bool runaway = false;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) runaway = runaway || (at[r] != kGroup && at[r] >= (1u << 28));
+            if (++spins > (1u << 20) || __ballot(runaway)) {
                 if (lane == 0) atomicAdd(ovf_cursor, ovf_cap + 1u);
                 break;
             }

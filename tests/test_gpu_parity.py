@@ -366,7 +366,8 @@ def test_skewed_repeats_overflow_and_fallback(hp, oracle, monkeypatch, strategy)
     off = np.cumsum([0] + [len(p) for p in parts]).astype(np.int64)
     ora = oracle.run(img, sb, off, lookup_mode=1)
     assert np.diff(ora["container_hit_start"]).max() > 40000 and ora["calls"]["count"].max() == 39998
-    variants = [{}] if strategy == "direct" else [{}, {"KG_PART_SLACK": "5"}, {"KG_PART_SLACK": "5", "KG_PART_OVF_GROUPS": "3"}]
+    variants = [{}] if strategy == "direct" else [{}, {"KG_PART_MIN_CHUNK_BLOCKS": "1", "KG_PART_CHUNKS": "3"}, {"KG_PART_SLACK": "5"},
+                                                  {"KG_PART_SLACK": "5", "KG_PART_OVF_GROUPS": "3"}]
     with hp.SignatureTable.from_bytes(img) as tab:
         for env in variants:
             for k, v in env.items():
