@@ -593,8 +593,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         const double mean = (double)blocks_per_wg * WIN / (double)part_buckets * (env_u32("KG_PART_SLACK", 100u) / 100.0);
         const uint32_t cap = (uint32_t)(((uint64_t)(mean + 6.0 * std::sqrt(mean) + 32.0) + 15) / 16 * 16);
         const uint64_t n_regions_total = (uint64_t)part_buckets * n_wg;               // per chunk
-        // overflow list of one chunk (groups)
-        const uint32_t ovf_cap = env_u32("KG_PART_OVF_GROUPS", (uint32_t)std::min<uint64_t>(1u << 21, std::max<uint64_t>(65536, n_regions_total * cap / 16 / 64)));
+        // overflow list of one chunk (groups): an eighth of the regions' capacity (low-complexity sequence: 3 % of the
+        // bases in homopolymer runs overflow ~5 % of the entries; beyond the list the scan falls back to direct probing)
+        const uint32_t ovf_cap = env_u32("KG_PART_OVF_GROUPS", (uint32_t)std::min<uint64_t>(1u << 23, std::max<uint64_t>(65536, n_regions_total * cap / 16 / 8)));
         uint64_t *d_ent = nullptr, *d_ovf_ent = nullptr;
         uint32_t *d_fill = nullptr, *d_ovf_bucket = nullptr, *d_next = nullptr, *d_ovfc = nullptr;
         unsigned long long *d_masks = nullptr;
@@ -680,12 +681,12 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                 if (counters) {
                     hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, s3, KG_PROBE_ARGS, cand_c,
                                        candused_c, ccur_c, ccap, KG_ULIST_ARGS);
-                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(64), dim3(256), 0, s3, KG_PROBE_ARGS,
+                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(1024), dim3(256), 0, s3, KG_PROBE_ARGS,
                                        ovf_bucket_c, ovf_ent_c, ovfc_c, ovf_cap, part_shift, KG_ULIST_ARGS);
                 } else {
                     hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, s3, KG_PROBE_ARGS, cand_c,
                                        candused_c, ccur_c, ccap, KG_ULIST_ARGS);
-                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(64), dim3(256), 0, s3, KG_PROBE_ARGS,
+                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(1024), dim3(256), 0, s3, KG_PROBE_ARGS,
                                        ovf_bucket_c, ovf_ent_c, ovfc_c, ovf_cap, part_shift, KG_ULIST_ARGS);
                 }
 #undef KG_TAG_ARGS
