@@ -13,6 +13,8 @@
 //                          bucket in the workgroup's LDS -> the workgroup's over-allocated region of the bucket
 //                          (no counting pass, no per-entry global atomics, no workgroup barrier in the main loop;
 //                          overflow list for skewed inputs)
+//   lowc_blocks_kernel   : the blocks the scatter pass set aside (low-complexity sequence: most windows in one or two
+//                          buckets): their entries are appended to the regions in whole same-bucket sets
 //   bucket_tag_kernel    : persistent workgroups; group x = blockIdx % 8 (XCD under round-robin placement,
 //                          speed only) walks the buckets b % 8 == x; per entry one 16-tag window out of L2: an
 //                          empty slot ends it, a fingerprint match or an undecided window becomes a 16-byte
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t block_lo, uint32_t n_blocks /* of this launch */,
     uint64_t limit, uint32_t num_sigs /* 64 <= num_sigs < 2^31 */, uint32_t m35, uint32_t shift, uint32_t n_buckets, uint32_t cap,
     uint64_t *__restrict__ ent, uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap, uint32_t *__restrict__ ovf_bucket,
-    uint64_t *__restrict__ ovf_ent, unsigned long long *ctr)
+    uint64_t *__restrict__ ovf_ent, uint32_t *lowc_cursor /* [0] count */, uint32_t *__restrict__ lowc_blocks, unsigned long long *ctr)
 {
     constexpr int ROWS = AA ? 1 : 6;
     typedef typename WaveLds<AA>::type Enc;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
         const uint32_t it = (iter * n_wg + w) * kScatterWaves + (uint32_t)wave;      // wave-uniform
         uint64_t e[ROWS];
         uint32_t bk[ROWS];
-        uint32_t pend = 0;
+        uint32_t pend = 0, n_valid_block = 0;
         if (it < n_blocks) {
             const BlockDesc bd = bd_next;
             uint32_t raw[4] = {raw_next[0], raw_next[1], raw_next[2], raw_next[3]};
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 uint32_t hi, lo, q;
                 bool valid = row_halves<AA>(l, r, lane, bd, &hi, &lo);
                 const uint32_t slot = split_fast(hi, lo, num_sigs, m35, &q);
-                if (valid) n_valid++;                                   // query k-mers (KGJ:913-920)
+                if (valid) { n_valid++; n_valid_block++; }              // query k-mers (KGJ:913-920)
                 valid = valid && slot < limit32;                        // beyond the stream: never probed
                 bk[r] = slot >> shift;
                 const uint32_t low = (q << shift) | (slot & ((1u << shift) - 1u));
@@ -170,6 +172,20 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 if (valid) pend |= 1u << r;
             }
             wave_sync();   // the wave's encode scratch is reused by its next block
+            // Low-complexity sequence (homopolymers, short tandem repeats): most windows of the block are one k-mer or
+            // two, and pushing them through one 16-entry buffer serialises the whole workgroup on it.  Such a block
+            // is not inserted here: it goes on a list for lowc_blocks_kernel, which appends its entries in bulk.
+            {
+                const unsigned long long m0 = __ballot((pend & 1u) != 0);
+                if (__popcll(m0) >= 32) {
+                    const uint32_t lead0 = (uint32_t)__builtin_amdgcn_readlane((int)bk[0], __builtin_ctzll(m0));
+                    if (__popcll(__ballot((pend & 1u) && bk[0] == lead0)) >= 24) {
+                        if (lane == 0) lowc_blocks[atomicAdd(lowc_cursor, 1u)] = block_lo + it;
+                        n_valid -= n_valid_block;                          // counted again by lowc_blocks_kernel
+                        pend = 0;
+                    }
+                }
+            }
         }
         // Insert without workgroup barriers.  A bucket's buffer is a 16-entry group with two counters:
         //   cnt[b]      tickets: atomicAdd gives the entry's place; >= 16 means "full, try again"
@@ -258,14 +274,19 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 if (has) { written[b] = 0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); cnt[b] = 0; }
             }
             if (!__ballot(pend != 0)) break;
-            // entries left: their buffers were full.  Wait until one of them reopens (bounded), then try again.
-            for (uint32_t polls = 0; polls < 64; polls++) {
-                bool open = false;
+            // entries left: their buffers were full.  Wait until a lane's first waiting buffer reopens (bounded), then try
+            // again.
+            {
+                const int rp = pend ? __builtin_ctz(pend) : 0;
+                uint32_t pb = bk[0];
 #pragma unroll
-                for (int r = 0; r < ROWS; r++)
-                    if (pend & (1u << r)) open = open || *const_cast<volatile uint32_t *>(&cnt[bk[r]]) < kGroup;
-                if (__ballot(open)) break;
-                __builtin_amdgcn_s_sleep(2);
+                for (int r = 1; r < ROWS; r++)
+                    if (rp == r) pb = bk[r];
+                const volatile uint32_t *pc = &cnt[pb];
+                for (uint32_t polls = 0; polls < 64; polls++) {
+                    if (__ballot(pend != 0 && *pc < kGroup)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
             }
             // Never expected (see above).  The second test keeps a ticket counter far from wrapping round to zero,
             // which would hand out the slots of a full buffer a second time.
@@ -283,6 +304,110 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     flush_wave(1u);
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) fill[(uint64_t)b * n_wg + w] = wrel[b];
+    for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
+    if (lane == 0 && n_valid) atomicAdd(&ctr[0], n_valid);
+}
+
+// ---------------------------------------------------------------------------------------
+// The blocks the scatter pass set aside (low-complexity sequence), one wave per block, after the scatter pass of the
+// chunk: encode again, then every row's same-bucket sets of >= 16 entries are appended to a region of that bucket in
+// one piece (padded to whole groups with fillers; regions are filled through fill[] with global atomics now -- the
+// scatter workgroups have published them), or to the overflow list when the region is full; what is left goes in
+// single entries.  Regions are picked by block number, so a long run spreads over all of a bucket's regions.
+template <bool AA>
+__global__ __launch_bounds__(256) void lowc_blocks_kernel(
+    const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, const uint32_t *__restrict__ lowc_cursor,
+    const uint32_t *__restrict__ lowc_blocks, uint64_t limit, uint32_t num_sigs, uint32_t m35, uint32_t shift, uint32_t n_regions,
+    uint32_t cap, uint64_t *__restrict__ ent, uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap,
+    uint32_t *__restrict__ ovf_bucket, uint64_t *__restrict__ ovf_ent, unsigned long long *ctr)
+{
+    constexpr int ROWS = AA ? 1 : 6;
+    __shared__ typename WaveLds<AA>::type lds[4];
+    __shared__ typename WaveLds<AA>::tables enc_tables;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    typename WaveLds<AA>::type &l = lds[wave];
+    encode_init<AA>(enc_tables, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const uint32_t limit32 = limit < 0xFFFFFFFFull ? (uint32_t)limit : 0xFFFFFFFFu;
+    const uint32_t n_list = *lowc_cursor;
+    unsigned long long n_valid = 0;
+    // one group (16 entries, fillers included) for `lead` on the overflow list; ~0 when the list is full
+    auto ovf_groups = [&](uint32_t lead, uint32_t ng) -> uint64_t * {
+        uint32_t g0 = 0;
+        if (lane == 0) g0 = atomicAdd(ovf_cursor, ng);
+        g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0);
+        if (g0 + ng > ovf_cap) return nullptr;                      // dropped: the host falls back to direct probing
+        if ((uint32_t)lane < ng) ovf_bucket[g0 + lane] = lead;
+        return ovf_ent + (uint64_t)g0 * kGroup;
+    };
+    for (uint32_t i = blockIdx.x * 4 + (uint32_t)wave; i < n_list; i += gridDim.x * 4) {
+        const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)lowc_blocks[i]);
+        const BlockDesc bd = blocks[it];
+        encode_block<AA>(l, enc_tables, seq, bd, lane);
+        const uint32_t region_w = it % n_regions;
+        for (int r = 0; r < ROWS; r++) {
+            uint32_t hi, lo, q;
+            bool valid = row_halves<AA>(l, r, lane, bd, &hi, &lo);
+            const uint32_t slot = split_fast(hi, lo, num_sigs, m35, &q);
+            if (valid) n_valid++;
+            bool pend = valid && slot < limit32;
+            const uint32_t bkt = slot >> shift;
+            const uint64_t e = ((uint64_t)((it << 9) | ((uint32_t)r << 6) | (uint32_t)lane) << 32) | ((q << shift) | (slot & ((1u << shift) - 1u)));
+            // big same-bucket sets first: one reservation and one coalesced store per set
+            for (int pass = 0; pass < 4; pass++) {
+                const unsigned long long mp = __ballot(pend);
+                if (__popcll(mp) < 16) break;
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)bkt, __builtin_ctzll(mp));
+                const bool mine = pend && bkt == lead;
+                const unsigned long long same = __ballot(mine);
+                const uint32_t n = (uint32_t)__popcll(same);
+                if (n < 8) break;                                     // a diverse row: single entries below
+                const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                const uint64_t region = (uint64_t)lead * n_regions + region_w;
+                uint32_t rel = 0;
+                if (lane == 0) rel = atomicAdd(&fill[region], n);
+                rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
+                if (rel + n <= cap) {
+                    if (mine) ent[region * cap + rel + rank] = e;
+                } else {
+                    // the set does not fit: what is left of the region stays empty (fillers), the set goes to the
+                    // overflow list in whole groups
+                    if (rel < cap && (uint32_t)lane < cap - rel) ent[region * cap + rel + lane] = kEntInvalid;
+                    const uint32_t npad = (n + kGroup - 1) & ~(kGroup - 1);
+                    uint64_t *dst = ovf_groups(lead, npad / kGroup);
+                    if (dst) {
+                        if (mine) dst[rank] = e;
+                        if ((uint32_t)lane < npad - n) dst[n + lane] = kEntInvalid;
+                    }
+                }
+                if (mine) pend = false;
+            }
+            // the rest one by one
+            if (pend) {
+                const uint64_t region = (uint64_t)bkt * n_regions + region_w;
+                const uint32_t rel = atomicAdd(&fill[region], 1u);
+                if (rel < cap) { ent[region * cap + rel] = e; pend = false; }
+            }
+            // ... and those whose region is full: overflow groups, one bucket per pass
+            for (;;) {
+                const unsigned long long mp = __ballot(pend);
+                if (!mp) break;
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)bkt, __builtin_ctzll(mp));
+                const bool mine = pend && bkt == lead;
+                const unsigned long long same = __ballot(mine);
+                const uint32_t n = (uint32_t)__popcll(same);
+                const uint32_t npad = (n + kGroup - 1) & ~(kGroup - 1);
+                const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                uint64_t *dst = ovf_groups(lead, npad / kGroup);
+                if (dst) {
+                    if (mine) dst[rank] = e;
+                    if ((uint32_t)lane < npad - n) dst[n + lane] = kEntInvalid;
+                }
+                if (mine) pend = false;
+            }
+        }
+        wave_sync();   // LDS is reused by the next block
+    }
     for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
     if (lane == 0 && n_valid) atomicAdd(&ctr[0], n_valid);
 }
@@ -418,7 +543,7 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
             const uint32_t g = s_region;
             if (g >= n_grabs) break;                    // bucket exhausted (uniform): next bucket of this group
             const uint32_t w = g / grabs_per_region, g0 = (g % grabs_per_region) * kGrab;
-            const uint32_t n = fill[(uint64_t)b * n_regions + w];
+            const uint32_t n = min(fill[(uint64_t)b * n_regions + w], cap);     // (bulk appends may have run past the region)
             const uint64_t *src = ent + ((uint64_t)b * n_regions + w) * cap;
             for (uint32_t c0 = g0; c0 < n && c0 < g0 + kGrab; c0 += 256u * N) {
                 uint64_t home[N], cur[N];

@@ -609,7 +609,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         if ((rc = sc.get(&d_ovf_bucket, (size_t)ovf_cap * n_chunks_p))) return rc;
         const size_t next_stride = (size_t)part_buckets + 8;
         if ((rc = sc.get(&d_next, next_stride * n_chunks_p))) return rc;
-        if ((rc = sc.get(&d_ovfc, 8 * kMaxChunks))) return rc;
+        if ((rc = sc.get(&d_ovfc, 8 * kMaxChunks))) return rc;       // per chunk: [0] overflow groups, [1] low-complexity blocks
+        uint32_t *d_lowc = nullptr;                                    // block numbers set aside by the scatter pass
+        if ((rc = sc.get(&d_lowc, (size_t)nblocks + 1))) return rc;
         if ((rc = sc.get(&d_masks, (size_t)n_rows))) return rc;
         if ((rc = sc.get(&d_info, (size_t)n_rows))) return rc;
         if ((rc = sc.get(&d_pc, 48))) return rc;
@@ -667,7 +669,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                 uint64_t *base_c = d_pc + 16 + c, *ctot_c = d_pc + 32 + c;
                 hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
                                    d_blocks, lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
-                                   cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, d_ctr);
+                                   cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, ovfc_c + 1, d_lowc + lo, d_ctr);
+                // the low-complexity blocks it set aside (usually none: the waves read the count and leave)
+                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(256), dim3(256), 0, t->stream, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
+                                   t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
+                                   ovf_bucket_c, ovf_ent_c, d_ctr);
                 HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
                 HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
                 hipStream_t s2 = t->stream2, s3 = t->stream3;
