@@ -331,14 +331,31 @@ __global__ __launch_bounds__(256) void lowc_blocks_kernel(
     const uint32_t limit32 = limit < 0xFFFFFFFFull ? (uint32_t)limit : 0xFFFFFFFFu;
     const uint32_t n_list = *lowc_cursor;
     unsigned long long n_valid = 0;
-    // one group (16 entries, fillers included) for `lead` on the overflow list; ~0 when the list is full
+    // Overflow groups come from a wave-private pool reserved 32 at a time: one returning atomic on the list's cursor
+    // per set would run at the ~90 per microsecond a single word sustains.  Unused pool groups are handed in empty.
+    uint32_t pool_at = 0, pool_end = 0;                             // wave-uniform
+    auto pool_flush = [&]() {
+        for (uint32_t g = pool_at + ((uint32_t)lane >> 4); g < pool_end && g < ovf_cap; g += 4) {
+            if ((lane & 15) == 0) ovf_bucket[g] = 0;
+            ovf_ent[(uint64_t)g * kGroup + ((uint32_t)lane & 15u)] = kEntInvalid;
+        }
+        pool_at = pool_end;
+    };
+    // ng groups (16 entries each, fillers included) for bucket `lead`; nullptr when the list is full
     auto ovf_groups = [&](uint32_t lead, uint32_t ng) -> uint64_t * {
-        uint32_t g0 = 0;
-        if (lane == 0) g0 = atomicAdd(ovf_cursor, ng);
-        g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0);
-        if (g0 + ng > ovf_cap) return nullptr;                      // dropped: the host falls back to direct probing
-        if ((uint32_t)lane < ng) ovf_bucket[g0 + lane] = lead;
-        return ovf_ent + (uint64_t)g0 * kGroup;
+        if (pool_end - pool_at < ng) {
+            pool_flush();
+            const uint32_t want = ng > 32u ? ng : 32u;
+            uint32_t g0 = 0;
+            if (lane == 0) g0 = atomicAdd(ovf_cursor, want);
+            g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0);
+            pool_at = g0; pool_end = g0 + want;
+        }
+        const uint32_t g = pool_at;
+        pool_at += ng;
+        if (g + ng > ovf_cap) return nullptr;                       // dropped: the host falls back to direct probing
+        if ((uint32_t)lane < ng) ovf_bucket[g + lane] = lead;
+        return ovf_ent + (uint64_t)g * kGroup;
     };
     for (uint32_t i = blockIdx.x * 4 + (uint32_t)wave; i < n_list; i += gridDim.x * 4) {
         const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)lowc_blocks[i]);
@@ -364,8 +381,8 @@ __global__ __launch_bounds__(256) void lowc_blocks_kernel(
                 if (n < 8) break;                                     // a diverse row: single entries below
                 const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
                 const uint64_t region = (uint64_t)lead * n_regions + region_w;
-                uint32_t rel = 0;
-                if (lane == 0) rel = atomicAdd(&fill[region], n);
+                uint32_t rel = cap;                                   // a region known to be full is not touched again
+                if (lane == 0 && *const_cast<volatile uint32_t *>(&fill[region]) < cap) rel = atomicAdd(&fill[region], n);
                 rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
                 if (rel + n <= cap) {
                     if (mine) ent[region * cap + rel + rank] = e;
@@ -408,6 +425,7 @@ __global__ __launch_bounds__(256) void lowc_blocks_kernel(
         }
         wave_sync();   // LDS is reused by the next block
     }
+    pool_flush();
     for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
     if (lane == 0 && n_valid) atomicAdd(&ctr[0], n_valid);
 }

@@ -671,7 +671,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                                    d_blocks, lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
                                    cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, ovfc_c + 1, d_lowc + lo, d_ctr);
                 // the low-complexity blocks it set aside (usually none: the waves read the count and leave)
-                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(256), dim3(256), 0, t->stream, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
+                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(512), dim3(256), 0, t->stream, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
                                    t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
                                    ovf_bucket_c, ovf_ent_c, d_ctr);
                 HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
