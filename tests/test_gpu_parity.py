@@ -443,3 +443,30 @@ def test_list_resize_and_rerun(hp, oracle, monkeypatch, strategy):
         with tab.scan(sb, off, hp.Params(min_hits=3)) as r:              # the table remembers the hit rate: one launch
             assert r.stats["scan_launches"] == 1
             assert_same_records(r, ora, "after resize " + strategy)
+
+
+def test_low_complexity_protein(hp, oracle, monkeypatch, strategy):
+    """Protein input with long single-residue and two-residue repeats (the scatter pass sets such blocks aside for
+    lowc_blocks_kernel); the repeated k-mers are signatures, so the hit lists run into the 39 998 cap."""
+    from kmergutsjava_amd import synth
+    import torch
+    kk = sum(8 * 20 ** i for i in range(8))                            # KKKKKKKK
+    kr = sum((8 if i % 2 else 14) * 20 ** i for i in range(8))         # KRKRKRKR / RKRKRKRK differ: add both
+    rk = sum((14 if i % 2 else 8) * 20 ** i for i in range(8))
+    keys = torch.unique(torch.cat([synth.random_keys(30000, 15), torch.tensor([kk, kr, rk])]))
+    rec, placed = synth.build_table(keys, synth.payload_of(keys, 16, n_otu=5, n_fn=7), 100003)
+    img = _img(rec)
+    rnd = synth.random_protein(6000, 17).numpy().tobytes()
+    parts = [b"K" * 50000, rnd[:3000], b"KR" * 21000 + b"MKV" + b"K" * 900, rnd[3000:], b"", b"R" * 70]
+    sb = b"".join(parts)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.int64)
+    ora = oracle.run(img, sb, off, aa=True, min_hits=2, lookup_mode=1)
+    assert np.diff(ora["container_hit_start"]).max() > 40000 and ora["calls"]["count"].max() == 39998
+    for env in ({}, {"KG_PART_MIN_CHUNK_BLOCKS": "1", "KG_PART_CHUNKS": "2"}, {"KG_PART_SLACK": "5"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with hp.SignatureTable.from_bytes(img) as tab:
+            with tab.scan(sb, off, hp.Params(aa=True, min_hits=2, counters=True)) as r:
+                assert_same_records(r, ora, "low-complexity protein %s %s" % (strategy, env))
+                assert r.stats["windows_valid"] == ora["windows_valid"]
+                assert r.stats["slots_inspected"] == ora["slots_inspected"]
