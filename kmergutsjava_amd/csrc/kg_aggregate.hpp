@@ -49,14 +49,14 @@ __device__ __forceinline__ int32_t rl(int32_t v, int k) { return __builtin_amdgc
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // processSetOfHits (KGJ:385-455) on the list [s.lo .. s.last].  chunk grid is anchored at `begin`
-// so that the chunk the caller is working on (cur_base, membership bits cur_mask) can be taken from
-// registers instead of acc[].
+// so that the chunk the caller is working on (cur_base, membership bits cur_mask, the lanes' fI and
+// functionWt) is taken from registers instead of memory.
 // returns bit 0: a CALL was made, bit 1: the last two members were kept
 template <bool EMIT>
 __device__ __forceinline__ uint32_t process_set(const kg_hit *__restrict__ h, const uint8_t *__restrict__ acc, uint32_t begin,
                                             const AggParams &p, AggState &s, uint32_t cur_base, uint64_t cur_mask,
-                                            uint32_t container, uint32_t call_at, kg_call *calls, CallSpan *spans,
-                                            bool allow_carry)
+                                            int32_t cur_fI, float cur_wt, uint32_t container, uint32_t call_at, kg_call *calls,
+                                            CallSpan *spans, bool allow_carry)
 {
     const int lane = threadIdx.x & 63;
     int32_t fICount = 0;
@@ -69,10 +69,14 @@ __device__ __forceinline__ uint32_t process_set(const kg_hit *__restrict__ h, co
         int32_t fI = 0;
         float wt = 0.f;
         bool mem = false;
-        if (in) {
+        if (b == cur_base) {                 // the caller's chunk: its records are in registers (dense inputs: most sets)
+            fI = cur_fI;
+            wt = cur_wt;
+            mem = in && ((cur_mask >> lane) & 1ull) != 0;
+        } else if (in) {
             fI = h[i].fI;
             wt = h[i].functionWt;
-            mem = (b == cur_base) ? ((cur_mask >> lane) & 1ull) != 0 : (acc[i] & KG_EV_ACCEPTED) != 0;
+            mem = (acc[i] & KG_EV_ACCEPTED) != 0;
         }
         uint64_t m = __ballot(in && mem && fI == s.currentFI);
         if (m) {
@@ -148,14 +152,17 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
     s.last_pos = s.last_fI = s.last_avg = s.prev_fI = 0;
     s.cnt = 0; s.currentFI = 0; s.ncalls = 0;
     int32_t carry_pos = 0, carry_fI = 0;            // fields of the record before this chunk
-    uint32_t tail_base = 0xFFFFFFFFu;               // last chunk and its membership bits, for the final flush
+    uint32_t tail_base = 0xFFFFFFFFu;               // last chunk, its membership bits and records, for the final flush
     uint64_t tail_mask = 0;
+    int32_t tail_fI = 0;
+    float tail_wt = 0.f;
 
     for (uint32_t base = begin; base < end; base += 64) {
         const int n = (int)min(64u, end - base);
         const uint32_t i = base + lane;
         int32_t pos = 0, fI = 0, avg = 0;
-        if (lane < n) { pos = hits[i].from0InProt; fI = hits[i].fI; avg = hits[i].avgOffFromEnd; }
+        float wt = 0.f;
+        if (lane < n) { pos = hits[i].from0InProt; fI = hits[i].fI; avg = hits[i].avgOffFromEnd; wt = hits[i].functionWt; }
         uint64_t accmask;
         EvMasks em = {0, 0, 0, 0, 0, 0};
 
@@ -171,12 +178,20 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
             // KGJ:477-478 with Java int wrap-around: last.from0InProt + maxGap < ph.from0InProt
             const bool gapf = !first && (int32_t)((uint32_t)ppos + (uint32_t)p.max_gap) < pos;
             const bool eqf = !first && fI == pfI;
-            uint64_t ev = __ballot(lane < n && (gapf || eqf));
             const uint64_t gapm = __ballot(gapf), eqm = __ballot(eqf);
+            const uint64_t inm = n == 64 ? ~0ull : ((1ull << n) - 1ull);
             int k0 = 0;
-            while (ev) {
+            for (;;) {
+                // The next record at which the machine does more than append: one behind a gap, or one that repeats its
+                // predecessor's function while that function is not the current one (KGJ:503-508).  The current
+                // function only changes at such records (or when an empty list restarts at k0), so in dense inputs --
+                // long runs of the current function -- whole runs are skipped with one ballot.
+                if (k0 >= n) break;
+                const int32_t cfi = s.cnt > 0 ? s.currentFI : rl(fI, k0);
+                const uint64_t neqm = __ballot(fI != cfi);
+                const uint64_t ev = (gapm | (eqm & neqm)) & inm & ~((1ull << k0) - 1ull);
+                if (!ev) break;
                 const int k = __builtin_ctzll(ev);
-                ev &= ev - 1;
                 if (k > k0) {                                           // records k0..k-1: plain appends
                     if (s.cnt == 0) { s.currentFI = rl(fI, k0); s.lo = base + k0; }     // KGJ:486-488
                     s.cnt += k - k0;
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                         s.last = ik - 1;
                         // no carry is possible here: a pair of equal, non-current fI at the end of the list
                         // would have fired the pair rule when its second record was appended
-                        what = process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, false);
+                        what = process_set<EMIT>(hits, acc, begin, p, s, base, accmask, fI, wt, c, call_at, calls, spans, false);
                     } else {
                         s.cnt = 0;
                     }
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                 s.cnt++;                                                                 // KGJ:496-497
                 if (s.cnt > 1 && s.currentFI != fk && ((eqm >> k) & 1)) {                // KGJ:503-508
                     s.last = ik; s.prev = ik - 1; s.last_fI = fk; s.prev_fI = fk;
-                    em.after(k, process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true));
+                    em.after(k, process_set<EMIT>(hits, acc, begin, p, s, base, accmask, fI, wt, c, call_at, calls, spans, true));
                 }
                 k0 = k + 1;
             }
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                 if (s.cnt > 0 && (int32_t)((uint32_t)s.last_pos + (uint32_t)p.max_gap) < pk) {      // KGJ:477-484
                     uint32_t what = 0;
                     if (s.cnt >= p.min_hits)
-                        what = process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true);
+                        what = process_set<EMIT>(hits, acc, begin, p, s, base, accmask, fI, wt, c, call_at, calls, spans, true);
                     else
                         s.cnt = 0;
                     em.before(k, what);
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                         accmask |= 1ull << k;
                     }
                     if (s.cnt > 1 && s.currentFI != fk && s.prev_fI == s.last_fI)                    // KGJ:503-508
-                        em.after(k, process_set<EMIT>(hits, acc, begin, p, s, base, accmask, c, call_at, calls, spans, true));
+                        em.after(k, process_set<EMIT>(hits, acc, begin, p, s, base, accmask, fI, wt, c, call_at, calls, spans, true));
                 }
             }
         }
@@ -260,10 +275,12 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
         carry_fI = rl(fI, n - 1);
         tail_base = base;
         tail_mask = accmask;
+        tail_fI = fI;
+        tail_wt = wt;
     }
     uint32_t tail = 0;
     if (s.cnt >= p.min_hits) {                                                                       // KGJ:511-513
-        tail = process_set<EMIT>(hits, acc, begin, p, s, tail_base, tail_mask, c, call_at, calls, spans, true) & 1u;
+        tail = process_set<EMIT>(hits, acc, begin, p, s, tail_base, tail_mask, tail_fI, tail_wt, c, call_at, calls, spans, true) & 1u;
     }
     if (!EMIT && lane == 0) { call_cnt[c] = s.ncalls; tail_ev[c] = (uint8_t)tail; }
 }
