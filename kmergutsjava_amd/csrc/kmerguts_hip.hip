@@ -462,8 +462,17 @@ struct Scratch {
 };
 
 template <bool AA>
-int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64_t *offsets, int64_t n_seqs, kg_result *res)
+int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8_t *h_seq /* host copy still to upload, or null */,
+              const int64_t *offsets, int64_t n_seqs, kg_result *res)
 {
+    // h_seq != null: d_seq is an empty device buffer of offsets[n_seqs] bytes; the characters are uploaded here -- chunk
+    // by chunk in front of each chunk's scatter pass (partitioned strategy: the upload of chunk c+1 runs while chunk c is
+    // scanned), or in one piece
+    bool seq_uploaded = h_seq == nullptr;
+    auto upload = [&](int64_t a, int64_t b) -> int {
+        if (h_seq && b > a) HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(d_seq) + a, h_seq + a, (size_t)(b - a), hipMemcpyHostToDevice, t->stream));
+        return KG_OK;
+    };
     constexpr uint32_t PER = AA ? 1 : 6;
     const bool counters = (p->flags & KG_F_COUNTERS) != 0;
     kg_stats &st = res->st;
@@ -574,13 +583,15 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
         const uint64_t min_chunk = std::max(1u, env_u32("KG_PART_MIN_CHUNK_BLOCKS", 1u << 20));   // ~200 Mbp; tests lower it
         while (want > 1 && nblocks / want < min_chunk) want--;
         std::vector<uint64_t> clo;                                                    // chunk c = blocks [clo[c], clo[c+1])
-        clo.push_back(0);
+        std::vector<int64_t> cseq;                                                    //         = sequences [cseq[c], cseq[c+1])
+        clo.push_back(0); cseq.push_back(0);
         for (uint32_t c = 1; c < want; c++) {
             const uint64_t target = nblocks * c / want;
-            const uint64_t cut = *std::lower_bound(ibase.begin(), ibase.end(), (uint32_t)target);   // a sequence start
-            if (cut > clo.back() && cut < nblocks) clo.push_back(cut);
+            const auto it = std::lower_bound(ibase.begin(), ibase.end(), (uint32_t)target);        // a sequence start
+            const uint64_t cut = *it;
+            if (cut > clo.back() && cut < nblocks) { clo.push_back(cut); cseq.push_back((int64_t)(it - ibase.begin())); }
         }
-        clo.push_back(nblocks);
+        clo.push_back(nblocks); cseq.push_back(n_seqs);
         const uint32_t n_chunks_p = (uint32_t)clo.size() - 1;
         uint64_t max_chunk = 0;
         for (uint32_t c = 0; c < n_chunks_p; c++) max_chunk = std::max(max_chunk, clo[c + 1] - clo[c]);
@@ -667,6 +678,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                 kg::CandRec *cand_c = d_cand + (uint64_t)c * ccap;
                 unsigned long long *ucur_c = (unsigned long long *)(d_pc + c), *ccur_c = (unsigned long long *)(d_pc + 8 + c);
                 uint64_t *base_c = d_pc + 16 + c, *ctot_c = d_pc + 32 + c;
+                if (!seq_uploaded && (rc = upload(offsets[cseq[c]], offsets[cseq[c + 1]]))) return rc;
                 hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
                                    d_blocks, lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
                                    cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, ovfc_c + 1, d_lowc + lo, d_ctr);
@@ -712,6 +724,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
                 if (c + 1 == n_chunks_p) HIP_TRY(hipEventRecord(t->ev[5], t->stream));   // all chunks scattered
             }
 #undef KG_PROBE_ARGS
+            seq_uploaded = true;
             HIP_TRY(hipEventRecord(t->pev[17], t->stream2));              // join
             HIP_TRY(hipStreamWaitEvent(t->stream, t->pev[17], 0));
             HIP_TRY(hipEventRecord(t->pev[18], t->stream3));
@@ -770,6 +783,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64
     }
     if (!part_done) {
         st.scan_launches = 0;
+        if (!seq_uploaded) { if ((rc = upload(offsets[0], offsets[n_seqs]))) return rc; seq_uploaded = true; }
     // ---- scan: encode + probe + staged compaction; re-run once if the staging area was too small ----
     // persistent grid: enough workgroups to fill 256 CUs, few enough that per-wave staging chunks stay small
     const uint32_t scan_grid = env_u32("KG_SCAN_GRID", 256u * 8u);
@@ -922,15 +936,12 @@ int scan_entry(kg_table *t, const kg_params *p, const uint8_t *seq, bool on_devi
     int rc = KG_OK;
     if (!on_device) {
         size_t end = (size_t)offsets[n_seqs];
-        rc = dalloc(t, (void **)&d_seq, end + 16);
-        if (rc == KG_OK && end) {
-            hipError_t e = hipMemcpyAsync(d_seq, seq, end, hipMemcpyHostToDevice, t->stream);
-            if (e != hipSuccess) rc = fail(KG_ERR_DEVICE, std::string("hipMemcpyAsync(seq): ") + hipGetErrorString(e));
-        }
+        rc = dalloc(t, (void **)&d_seq, end + 16);       // filled by scan_impl (upload overlapped with the scan where possible)
     }
     if (rc == KG_OK) {
         const uint8_t *s = on_device ? seq : d_seq;
-        rc = p->aa ? scan_impl<true>(t, p, s, offsets, n_seqs, r) : scan_impl<false>(t, p, s, offsets, n_seqs, r);
+        const uint8_t *h = on_device ? nullptr : seq;
+        rc = p->aa ? scan_impl<true>(t, p, s, h, offsets, n_seqs, r) : scan_impl<false>(t, p, s, h, offsets, n_seqs, r);
     }
     (void)hipStreamSynchronize(t->stream);
     if (d_seq) dfree(t, d_seq);
