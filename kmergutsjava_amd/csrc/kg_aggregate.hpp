@@ -138,13 +138,30 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restrict__ hits, const int64_t *__restrict__ chs,
                                                          uint32_t n_cont, AggParams p, uint8_t *acc, uint8_t *tail_ev,
                                                          uint32_t *call_cnt, const uint32_t *call_off, kg_call *calls,
-                                                         CallSpan *spans)
+                                                         CallSpan *spans, uint32_t per_wave)
 {
+    // per_wave consecutive containers per wave: 1 for few long containers (contigs); more for millions of short ones
+    // (reads), where launching a wave per container would cost more than the work
     const int lane = threadIdx.x & 63;
-    const uint32_t c = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (c >= n_cont) return;
-    if (EMIT && call_cnt[c] == 0) return;          // nothing to write; acc[] was filled by the counting pass
-    const uint32_t begin = (uint32_t)chs[c], end = (uint32_t)chs[c + 1];
+    const uint32_t c_first = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6))) * per_wave;
+    // The wave's containers' extents in one coalesced load (per_wave <= 64).  Containers with fewer than two hits need
+    // no machine (minHits >= 2: no CALL; a single hit is simply accepted, KGJ:486-497): lanes settle them directly and
+    // the sequential part below visits only the others.
+    uint32_t my_begin = 0, my_end = 0;
+    const bool mine = (uint32_t)lane < per_wave && c_first + (uint32_t)lane < n_cont;
+    if (mine) { my_begin = (uint32_t)chs[c_first + lane]; my_end = (uint32_t)chs[c_first + lane + 1]; }
+    if (!EMIT && mine && my_end - my_begin < 2) {
+        call_cnt[c_first + lane] = 0;
+        tail_ev[c_first + lane] = 0;
+        if (my_end != my_begin) acc[my_begin] = (uint8_t)KG_EV_ACCEPTED;
+    }
+    uint64_t todo = __ballot(mine && my_end - my_begin >= 2);
+    while (todo) {
+    const int ci = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const uint32_t c = c_first + (uint32_t)ci;
+    if (EMIT && call_cnt[c] == 0) continue;        // nothing to write; acc[] was filled by the counting pass
+    const uint32_t begin = (uint32_t)rl((int32_t)my_begin, ci), end = (uint32_t)rl((int32_t)my_end, ci);
     const uint32_t call_at = EMIT ? call_off[c] : 0;
 
     AggState s;
@@ -283,6 +300,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
         tail = process_set<EMIT>(hits, acc, begin, p, s, tail_base, tail_mask, tail_fI, tail_wt, c, call_at, calls, spans, true) & 1u;
     }
     if (!EMIT && lane == 0) { call_cnt[c] = s.ncalls; tail_ev[c] = (uint8_t)tail; }
+    }
 }
 
 // ccs[c] = call_off[c] widened, plus sentinel
@@ -300,11 +318,11 @@ __global__ void call_starts_kernel(const uint32_t *call_off, uint64_t n_cont, co
 __global__ __launch_bounds__(256) void otu_wave_kernel(const kg_hit *__restrict__ hits, const uint8_t *__restrict__ acc,
                                                        const kg_call *__restrict__ calls, const CallSpan *__restrict__ spans,
                                                        const int64_t *__restrict__ ccs, uint32_t n_seqs, uint32_t per,
-                                                       kg_otu *otu)
+                                                       kg_otu *otu, uint32_t per_wave)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t s = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (s >= n_seqs) return;
+    const uint32_t s_first = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6))) * per_wave;
+    for (uint32_t s = s_first; s < s_first + per_wave && s < n_seqs; s++) {
     int32_t n = 0;
     int32_t cnt[KG_OI_BUFSZ] = {0, 0, 0, 0, 0}, oi[KG_OI_BUFSZ] = {0, 0, 0, 0, 0};
     const int64_t c0 = ccs[(uint64_t)s * per], c1 = ccs[(uint64_t)(s + 1) * per];
@@ -353,6 +371,7 @@ __global__ __launch_bounds__(256) void otu_wave_kernel(const kg_hit *__restrict_
 #pragma unroll
         for (int k = 0; k < KG_OI_BUFSZ; k++) { r.count[k] = k < n ? cnt[k] : 0; r.oI[k] = k < n ? oi[k] : 0; }
         otu[s] = r;
+    }
     }
 }
 

@@ -874,11 +874,13 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if ((rc = sc.get(&d_coff, n_cont))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_ccs, (n_cont + 1) * 8))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_otu, (size_t)(n_seqs ? n_seqs : 1) * sizeof(kg_otu)))) return rc;
-        uint32_t cgrid = (uint32_t)((n_cont + 3) / 4);           // one wave per container
+        // one wave per container; several consecutive containers per wave when there are millions of them (short reads)
+        const uint32_t cpw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, n_cont / (1u << 17)));
+        uint32_t cgrid = (uint32_t)(((n_cont + cpw - 1) / cpw + 3) / 4);
         if (n_cont) {
             hipLaunchKernelGGL((kg::calls_wave_kernel<false>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
                                (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, (const uint32_t *)nullptr, (kg_call *)nullptr,
-                               (kg::CallSpan *)nullptr);
+                               (kg::CallSpan *)nullptr, cpw);
             HIP_TRY(hipGetLastError());
         }
         if ((rc = prefix_sum(t, d_ccnt, n_cont, d_coff, d_partial, d_totals + 4))) return rc;
@@ -890,13 +892,14 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if ((rc = sc.get(&d_spans, n_calls))) return rc;
         if (n_cont && n_calls) {
             hipLaunchKernelGGL((kg::calls_wave_kernel<true>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
-                               (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, d_coff, res->d_calls, d_spans);
+                               (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, d_coff, res->d_calls, d_spans, cpw);
         }
         hipLaunchKernelGGL(kg::call_starts_kernel, dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream, d_coff,
                            n_cont, d_totals + 4, res->d_ccs);
         if (n_seqs) {
-            hipLaunchKernelGGL(kg::otu_wave_kernel, dim3((uint32_t)((n_seqs + 3) / 4)), dim3(256), 0, t->stream, res->d_hits,
-                               d_acc, res->d_calls, d_spans, res->d_ccs, (uint32_t)n_seqs, PER, res->d_otu);
+            const uint32_t spw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (uint64_t)n_seqs / (1u << 17)));
+            hipLaunchKernelGGL(kg::otu_wave_kernel, dim3((uint32_t)((((uint64_t)n_seqs + spw - 1) / spw + 3) / 4)), dim3(256), 0, t->stream,
+                               res->d_hits, d_acc, res->d_calls, d_spans, res->d_ccs, (uint32_t)n_seqs, PER, res->d_otu, spw);
         }
         HIP_TRY(hipGetLastError());
     }
