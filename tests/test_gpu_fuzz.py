@@ -1,6 +1,7 @@
-"""Differential fuzz of the two scan strategies (tools/fuzz_strategies.py): random tables, sequences with planted
-signatures and low-complexity runs, parameters, forced chunking, tiny regions and lists; every record kind and the event
-bytes must be byte-identical between direct and partitioned probing."""
+"""Differential fuzz (tests/fuzz_workloads.py: random tables, sequences with planted signatures and low-complexity
+runs, parameters, forced chunking, tiny regions and lists):
+  * both scan strategies against the CPU oracle, record for record, events included;
+  * tools/fuzz_strategies.py (direct vs partitioned only, no oracle) as a subprocess."""
 import json
 import os
 import subprocess
@@ -8,14 +9,39 @@ import sys
 
 import pytest
 
+from fuzz_workloads import workloads
+from helpers import assert_same_records
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_SLACK", "KG_TEST_TINY_LISTS", "KG_PART_OVF_GROUPS")
 
 
-@pytest.mark.parametrize("seed", [3, 4])
-def test_strategies_agree_on_random_workloads(seed):
-    env = {k: v for k, v in os.environ.items() if not k.startswith("KG_P") and k != "KG_TEST_TINY_LISTS"}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_strategies.py"), "30", str(seed)], stdout=subprocess.PIPE,
+@pytest.mark.parametrize("seed", [21, 22])
+def test_both_strategies_against_the_oracle(oracle, monkeypatch, seed):
+    from kmergutsjava_amd import hotpath
+    n_part = 0
+    for w in workloads(25, seed):
+        p = w["params"]
+        ora = oracle.run(w["img"], w["raw"], w["off"], lookup_mode=1, **p)
+        with hotpath.SignatureTable.from_bytes(w["img"]) as tab:
+            for mode in ("0", "1"):
+                for k in KNOBS:
+                    monkeypatch.delenv(k, raising=False)
+                monkeypatch.setenv("KG_PARTITION", mode)
+                if mode == "1":
+                    for k, v in w["env"].items():
+                        monkeypatch.setenv(k, v)
+                with tab.scan(w["raw"], w["off"], hotpath.Params(counters=True, **p)) as r:
+                    assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s" % (seed, w["it"], mode, w["env"]))
+                    assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
+                    n_part += r.stats["partitioned"]
+    assert n_part >= 15
+
+
+def test_strategies_agree_on_random_workloads():
+    env = {k: v for k, v in os.environ.items() if k not in KNOBS}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_strategies.py"), "30", "3"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=env, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-2000:]
     last = json.loads(r.stdout.decode().strip().splitlines()[-1])
