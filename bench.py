@@ -5,9 +5,11 @@ One "step" = one pass of the hot path (6-frame translate -> base-20 encode -> si
 probe -> ordered hit compaction -> CALL / OTU aggregation) over one batch of synthetic contigs
 that is already resident in HBM, through the C ABI (kg_scan_device).  Workload = BASELINE.json
 configs[2] (== the metric's configuration): 1 Gbp metagenome-like contig mix against a full-size
-KmerGuts signature table.  With N ranks every rank scans its own 1 Gbp
-shard against its own replica of the table (weak scaling) and the CALL / OTU records are gathered
-to rank 0 with RCCL inside the timed region.
+KmerGuts signature table.  With N ranks (BASELINE.json configs[3]) the SAME
+1 Gbp contig list is cut into N shards of whole contigs (strong scaling, the default; every rank
+generates only its shard), each rank scans its shard against its own replica of the table, and the
+per-rank CALL / OTU / hit buffers are gathered to rank 0 over RCCL inside the timed region, device
+buffer to device buffer.  --scaling weak gives every rank its own 1 Gbp instead.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
@@ -42,7 +44,14 @@ def main():
     ap.add_argument("--num-sigs", type=int, default=1_400_303_159, help="signature table slots (x 24 B)")
     ap.add_argument("--load", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-bp", type=int, default=10_000_000)
+    ap.add_argument("--cpu-sample-bp", type=int, default=100_000_000,
+                    help="prefix of the contig list the CPU baseline is timed on (BASELINE.md section 3: >= 100 Mbp, "
+                         "in batches of <= 20 M query k-mers)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the one --total-bp contig list sharded over the ranks (BASELINE config 4), "
+                         "weak = --total-bp per rank")
+    ap.add_argument("--no-gather-hits", action="store_true",
+                    help="N > 1: gather only CALL / OTU records to rank 0; hit records stay sharded in HBM")
     ap.add_argument("--strategy", choices=["auto", "direct", "partitioned"], default="auto",
                     help="scan strategy of the library (KG_PARTITION): auto picks partitioned probing for large inputs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
@@ -79,21 +88,37 @@ def main():
         (args.num_sigs, placed, args.num_sigs * 24 / 1e9, time.time() - t0))
     tab = hotpath.SignatureTable.from_device_ptr(rec.data_ptr(), args.num_sigs, local_rank, keepalive=rec)
 
-    lens = synth.contig_mix_lengths(args.total_bp, 301)                 # same length mix, different bases per rank
+    all_lens = synth.contig_mix_lengths(args.total_bp, 301)
+    all_off = synth.offsets_of(all_lens)
+    strong = args.scaling == "strong" or world == 1
+    if world == 1:
+        mine, n_total = np.arange(len(all_lens), dtype=np.int64), len(all_lens)
+        lens, seq = all_lens, synth.random_dna(int(all_off[-1]), 302, dev)
+    elif strong:
+        # the one contig list, whole contigs balanced over the ranks; a contig has the bases it has in the unsharded batch
+        mine, n_total = kd.shard_sequences(all_lens, world)[rank], len(all_lens)
+        lens = all_lens[mine]
+        seq = synth.random_dna_at(all_off[mine], lens, 302, dev)
+    else:
+        # every rank its own total_bp: same length mix, different bases; global contig k * world + rank
+        mine, n_total = np.arange(len(all_lens), dtype=np.int64) * world + rank, len(all_lens) * world
+        lens, seq = all_lens, synth.random_dna(int(all_off[-1]), 302, dev, start=rank * args.total_bp)
     off = synth.offsets_of(lens)
-    seq = synth.random_dna(int(off[-1]), 302, dev, start=rank * args.total_bp)
     torch.cuda.synchronize()
-    log("[bench] rank %d: %d contigs, %d bp" % (rank, len(lens), int(off[-1])))
+    log("[bench] rank %d: %d contigs, %d bp (%s)" % (rank, len(lens), int(off[-1]), "strong" if strong else "weak"))
 
     params = hotpath.Params()                      # reference defaults: -m 5 -g 200
     gather_dev = comm_dev
+    on_gpu = comm_dev.type == "cuda"
 
     def step():
         with tab.scan(None, off, params, device_ptr=seq.data_ptr()) as r:
             st = r.stats
             if world > 1:
-                local = {"calls": r.calls(), "otu": r.otu()}
-                kd.gather_records(local, np.arange(len(lens)) * world + rank, len(lens) * world, 6, gather_dev)
+                # the exchange step: per-rank record buffers -> rank 0, straight out of the library's HBM buffers
+                kinds = ("calls", "otu") + (() if args.no_gather_hits else ("hits", "container_hit_start"))
+                local = {k: (r.device_view(k) if on_gpu else r.device_view(k).cpu()) for k in kinds}
+                kd.gather_records(local, mine, n_total, 6, gather_dev)
             else:
                 r.calls(); r.otu()                 # the records the report needs leave HBM
             return st
@@ -142,14 +167,17 @@ def main():
     if rank == 0:
         ms_scan = float(np.mean(scan_ms))
         achieved = b_alg * residues / (ms_scan * 1e-3) / 1e9          # GB/s, algorithmic bytes / scan-kernel time
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")        # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:
             try:
                 tj = json.load(open(tpath))
                 if (tj.get("total_bp") == args.total_bp and tj.get("num_sigs") == args.num_sigs and
                         tj.get("strategy") == ("partitioned" if partitioned else "direct")):
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "command, FETCH doubled per MI355X_MICROARCH.md; not measured in this run"
+                                      % tj.get("round", "?"))
             except Exception:
                 traffic = None
         out = {
@@ -158,18 +186,29 @@ def main():
             "unit": "residues/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong and world > 1 else "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
             "hits_per_s": hits_all * args.steps / elapsed,
-            "config": {"workload": "1 Gbp contig mix (0.5 kbp..1.024 Mbp, uniform ACGT) per GPU, 6-frame translate + "
+            "config": {"workload": "%.3g Gbp contig mix (0.5 kbp..1.024 Mbp, uniform ACGT) %s, 6-frame translate + "
                                    "8-mer lookup vs %d-slot signature table (%.1f GB, load %.2f), -m 5 -g 200"
-                                   % (args.num_sigs, args.num_sigs * 24 / 1e9, args.load),
-                       "total_bp_per_gpu": int(off[-1]), "contigs_per_gpu": int(len(lens)),
-                       "num_sigs": args.num_sigs, "residues_per_gpu": int(residues),
-                       "hits_per_gpu": int(hits), "calls_per_gpu": int(calls),
+                                   % (args.total_bp / 1e9, "per GPU" if not strong else
+                                      ("on 1 GPU" if world == 1 else "cut into %d shards of whole contigs, one per GPU" % world),
+                                      args.num_sigs, args.num_sigs * 24 / 1e9, args.load),
+                       "total_bp_rank0": int(off[-1]), "contigs_rank0": int(len(lens)),
+                       "total_bp_all_ranks": int(all_off[-1]) * (1 if strong else world),
+                       "num_sigs": args.num_sigs, "residues_rank0": int(residues), "residues_all_ranks": int(residues_all),
+                       "hits_rank0": int(hits), "hits_all_ranks": int(hits_all), "calls_rank0": int(calls),
+                       "exchange": (None if world == 1 else "per-rank %s buffers -> rank 0, %s point-to-point, device buffers"
+                                    % ("CALL/OTU" if args.no_gather_hits else "CALL/OTU/hit",
+                                       "RCCL" if args.backend == "nccl" else args.backend)),
                        "parallelism": "contig shards x%d, table replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "bound_note": ("priced against HBM as SURVEY 8d prescribes; the partitioned scan moves fewer HBM "
+                                        "bytes than the algorithmic count and its passes are bound by VALU/LDS issue "
+                                        "(scatter), L2/LDS tag reads (tag pass) and random HBM lines (verification): "
+                                        "DESIGN.md section 6") if partitioned else
+                                       "direct probing: every 16-byte probe moves a 128-byte line from HBM",
                          "kernel": ("scan stage = kg::part_scatter_kernel || kg::bucket_tag_kernel || kg::verify_kernel + "
                                     "kg::place_unordered_kernel (chunks of whole contigs on three streams)" if partitioned else "kg::scan_kernel<false,false,3>"),
                          "kernel_ms": ms_scan,
@@ -190,11 +229,13 @@ def main():
 
 
 def cpu_baseline(args, rec, seq, off, tab):
-    """The C restatement of the reference algorithm (oracle/, literal sorted merge-join, 1 thread)
-    timed on the first contigs of the same workload against the same table.  Its records are also the checker
-    for the full-size GPU scan: the hit / CALL / OTU records of these contigs must be byte-identical."""
+    """The C restatement of the reference algorithm (oracle/, literal sorted merge-join, 1 thread) timed on a prefix
+    of the same workload against the same table, in batches of <= 20 M query k-mers (the reference's loss-free
+    regime, KGJ:108, 832).  Its records are also the checker for the full-size GPU scan: the hit / CALL / OTU records
+    of the prefix AND of a second sample of contigs drawn from every chunk of the GPU pipeline must be byte-identical."""
     import struct
     from oracle import kgo
+    from kmergutsjava_amd import hotpath, synth
     kgo.build()
     n = int(np.searchsorted(off, args.cpu_sample_bp, side="right"))
     n = max(1, min(n, len(off) - 1))
@@ -211,20 +252,30 @@ def cpu_baseline(args, rec, seq, off, tab):
     phases = o["t_prepare"] + o["t_lookup"] + o["t_group"]
     log("[bench] cpu_baseline: %d residues in %.1f s (prepare %.1f, lookup %.1f, group %.1f)" %
         (o["residues"], wall, o["t_prepare"], o["t_lookup"], o["t_group"]))
-    # parity of the full-size scan (all chunks, same strategy as the timed steps) on the sample's containers
-    from kmergutsjava_amd import hotpath
+    # parity of the full-size scan (same strategy as the timed steps)
     with tab.scan(None, off, hotpath.Params(), device_ptr=seq.data_ptr()) as r:
-        chs, ccs = r.container_hit_start(), r.container_call_start()
-        nc = n * 6
-        g_hits, g_calls, g_otu = r.hits()[:int(chs[nc])], r.calls()[:int(ccs[nc])], r.otu()[:n]
-        same = (g_hits.tobytes() == o["hits"].tobytes() and g_calls.tobytes() == o["calls"].tobytes() and
-                g_otu.tobytes() == o["otu"].tobytes() and np.array_equal(chs[:nc + 1], o["container_hit_start"]))
-        parity = {"contigs": n, "hits": int(len(o["hits"])), "calls": int(len(o["calls"])), "identical": bool(same),
+        n_chunks = max(1, r.stats["part_chunks"])
+        idx = synth.spread_sample(off, groups=max(4, n_chunks), per_group=20, max_bp_per_group=2_500_000)
+        sub_off = synth.offsets_of((off[1:] - off[:-1])[idx])
+        sub = torch.cat([seq[int(off[i]):int(off[i + 1])] for i in idx]).cpu().numpy()
+        o2 = kgo.run(host.numpy(), sub, sub_off, lookup_mode=0)
+
+        def same(got, ora):
+            return bool(all(got[k].tobytes() == ora[k].tobytes() for k in ("hits", "calls", "otu")) and
+                        np.array_equal(got["container_hit_start"], ora["container_hit_start"]) and
+                        np.array_equal(got["container_call_start"], ora["container_call_start"]))
+        ok_prefix = same(r.subset(np.arange(n)), o)
+        ok_spread = same(r.subset(idx), o2)
+        parity = {"prefix_contigs": n, "prefix_hits": int(len(o["hits"])), "prefix_identical": ok_prefix,
+                  "chunks": int(r.stats["part_chunks"]), "spread_contigs": int(len(idx)),
+                  "spread_contig_range": [int(idx[0]), int(idx[-1])], "spread_hits": int(len(o2["hits"])),
+                  "spread_calls": int(len(o2["calls"])), "spread_identical": ok_spread,
+                  "identical": ok_prefix and ok_spread,
                   "strategy": "partitioned" if r.stats["partitioned"] else "direct"}
-    log("[bench] parity of the full-size scan on the sample: %s" % parity)
-    assert same, "full-size GPU scan differs from the oracle on the sample contigs"
+    log("[bench] parity of the full-size scan on the samples: %s" % parity)
+    assert parity["identical"], "full-size GPU scan differs from the oracle on the sample contigs"
     return {"value": o["residues"] / phases, "unit": "residues/s", "cores": 1, "kind": "port", "parity_sample": parity,
-            "sample": "first %d contigs (%d bp, %d residues, %d query k-mers: one <=20 M-k-mer batch) of the same "
+            "sample": "first %d contigs (%d bp, %d residues, %d query k-mers, in batches of <= 20 M k-mers) of the same "
                       "contig mix against the same table; C restatement of the reference's materialise -> sort by "
                       "(value %% numSigs, value) -> streamed merge-join -> gatherHits, single thread"
                       % (n, int(sample_off[-1]), o["residues"], o["windows_valid"]),

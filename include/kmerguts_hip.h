@@ -110,7 +110,14 @@ typedef struct kg_stats {
     float   ms_part_scatter;     /* partitioned only: start of ms_scan until the last chunk is scattered        */
     float   ms_part_tag;         /* (unused: the tag passes overlap the scatter passes of later chunks)         */
     float   ms_part_verify;      /* partitioned only: what remains of the tag / verify passes after that        */
-    float   reserved;
+    int32_t fallback;            /* why a partitioned attempt was thrown away and the direct kernel ran instead:  */
+                                 /* 0 none (partitioned ran, or direct was chosen up front), 1 more overflow      */
+                                 /* groups than provisioned (heavily repeated k-mers), 2 the scatter pass's spin  */
+                                 /* guard fired (protocol failure; never expected)                                */
+    int32_t part_chunks;         /* partitioned only: chunks of whole sequences the batch was cut into            */
+    int32_t part_buckets;        /* partitioned only: slot-range buckets (each 2^part_shift slots)                */
+    int32_t part_shift;
+    int32_t reserved;
 } kg_stats;
 
 typedef struct kg_table  kg_table;
@@ -154,6 +161,8 @@ const uint8_t *kg_result_container_tail_events(kg_result *r);/* n_containers byt
 const void    *kg_result_device_hits(const kg_result *r);
 const void    *kg_result_device_calls(const kg_result *r);
 const void    *kg_result_device_otu(const kg_result *r);
+const void    *kg_result_device_container_hit_start(const kg_result *r);   /* int64[n_containers + 1] */
+const void    *kg_result_device_container_call_start(const kg_result *r);  /* int64[n_containers + 1], NULL with KG_F_SKIP_AGGREGATE */
 void kg_result_free(kg_result *r);
 
 const char *kg_last_error(void);

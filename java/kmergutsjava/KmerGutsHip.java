@@ -38,11 +38,12 @@ public interface KmerGutsHip extends Library {
                 slots_inspected, table_bytes;
         public float ms_scan, ms_order, ms_aggregate, ms_total;
         public int scan_launches, partitioned;
-        public float ms_part_scatter, ms_part_tag, ms_part_verify, reserved;
+        public float ms_part_scatter, ms_part_tag, ms_part_verify;
+        public int fallback, part_chunks, part_buckets, part_shift, reserved;
         @Override protected List<String> getFieldOrder() {
             return Arrays.asList("n_seqs", "n_containers", "n_blocks", "n_hits", "n_calls", "residues", "windows",
                     "windows_valid", "slots_inspected", "table_bytes", "ms_scan", "ms_order", "ms_aggregate",
-                    "ms_total", "scan_launches", "partitioned", "ms_part_scatter", "ms_part_tag", "ms_part_verify", "reserved");
+                    "ms_total", "scan_launches", "partitioned", "ms_part_scatter", "ms_part_tag", "ms_part_verify", "fallback", "part_chunks", "part_buckets", "part_shift", "reserved");
         }
     }
 
@@ -69,6 +70,8 @@ public interface KmerGutsHip extends Library {
     Pointer kg_result_device_hits(Pointer result);
     Pointer kg_result_device_calls(Pointer result);
     Pointer kg_result_device_otu(Pointer result);
+    Pointer kg_result_device_container_hit_start(Pointer result);
+    Pointer kg_result_device_container_call_start(Pointer result);
     void kg_result_free(Pointer result);
 
     String kg_last_error();

@@ -23,7 +23,8 @@ EXPORTS = (
     "kg_table_open", "kg_table_from_memory", "kg_table_from_device", "kg_table_info", "kg_table_close",
     "kg_scan", "kg_scan_device", "kg_result_stats", "kg_result_hits", "kg_result_container_hit_start",
     "kg_result_calls", "kg_result_container_call_start", "kg_result_otu", "kg_result_hit_events",
-    "kg_result_container_tail_events", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu", "kg_result_free", "kg_last_error", "kg_version",
+    "kg_result_container_tail_events", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu",
+    "kg_result_device_container_hit_start", "kg_result_device_container_call_start", "kg_result_free", "kg_last_error", "kg_version",
 )
 
 # event bits (include/kmerguts_hip.h KG_EV_*)
@@ -51,7 +52,8 @@ class KgStats(C.Structure):
                 ("table_bytes", C.c_int64), ("ms_scan", C.c_float), ("ms_order", C.c_float),
                 ("ms_aggregate", C.c_float), ("ms_total", C.c_float), ("scan_launches", C.c_int32),
                 ("partitioned", C.c_int32), ("ms_part_scatter", C.c_float), ("ms_part_tag", C.c_float),
-                ("ms_part_verify", C.c_float), ("reserved", C.c_float)]
+                ("ms_part_verify", C.c_float), ("fallback", C.c_int32), ("part_chunks", C.c_int32),
+                ("part_buckets", C.c_int32), ("part_shift", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -88,7 +90,8 @@ def load() -> C.CDLL:
     lib.kg_result_stats.argtypes = [vp, C.POINTER(KgStats)]
     for name in ("kg_result_hits", "kg_result_container_hit_start", "kg_result_calls",
                  "kg_result_container_call_start", "kg_result_otu", "kg_result_hit_events",
-                 "kg_result_container_tail_events", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu"):
+                 "kg_result_container_tail_events", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu",
+                 "kg_result_device_container_hit_start", "kg_result_device_container_call_start"):
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = vp
     lib.kg_result_free.argtypes = [vp]

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
         // atomic instead (16 waves on one counter: homopolymer runs) starves the flushing wave and can run the
         // 32-bit ticket counter round to zero, which hands out a full buffer's slots again (seen as an intermittent
         // stall before the polling loop existed).  The guards turn any remaining protocol failure into the host's
-        // fallback to the direct strategy (overflow > cap) instead of a hang or a wrong result.
+        // fallback to the direct strategy (sticky word ovf_cursor[2], kg_stats.fallback == 2) instead of a hang or a
+        // wrong result.
         uint32_t done = 0, spins = 0;
         for (;;) {
             uint32_t at[ROWS];
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
 #pragma unroll
             for (int r = 0; r < ROWS; r++) runaway = runaway || (at[r] != kGroup && at[r] >= (1u << 28));
             if (++spins > (1u << 20) || __ballot(runaway)) {
-                if (lane == 0) atomicAdd(ovf_cursor, ovf_cap + 1u);
+                if (lane == 0) atomicOr(ovf_cursor + 2, 1u);           // sticky "protocol failure" word (ovf_cursor stays a group count)
                 break;
             }
         }
@@ -326,10 +327,11 @@ __global__ __launch_bounds__(256) void lowc_blocks_kernel(
     __shared__ typename WaveLds<AA>::tables enc_tables;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     typename WaveLds<AA>::type &l = lds[wave];
+    const uint32_t n_list = *lowc_cursor;
+    if (n_list == 0) return;                                        // clean input: nothing was set aside (uniform)
     encode_init<AA>(enc_tables, threadIdx.x, blockDim.x);
     __syncthreads();
     const uint32_t limit32 = limit < 0xFFFFFFFFull ? (uint32_t)limit : 0xFFFFFFFFu;
-    const uint32_t n_list = *lowc_cursor;
     unsigned long long n_valid = 0;
     // Overflow groups come from a wave-private pool reserved 32 at a time: one returning atomic on the list's cursor
     // per set would run at the ~90 per microsecond a single word sustains.  Unused pool groups are handed in empty.

@@ -682,13 +682,15 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
                                    d_blocks, lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
                                    cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, ovfc_c + 1, d_lowc + lo, d_ctr);
-                // the low-complexity blocks it set aside (usually none: the waves read the count and leave)
-                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(512), dim3(256), 0, t->stream, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
-                                   t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
-                                   ovf_bucket_c, ovf_ent_c, d_ctr);
                 HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
                 HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
                 hipStream_t s2 = t->stream2, s3 = t->stream3;
+                // the low-complexity blocks the scatter pass set aside (usually none: every workgroup reads the count and
+                // leaves).  In front of the chunk's tag pass, not behind its scatter pass: the scatter stream goes straight
+                // on to the next chunk instead of waiting for 512 workgroups to find room beside the resident tag kernel.
+                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(512), dim3(256), 0, s2, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
+                                   t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
+                                   ovf_bucket_c, ovf_ent_c, d_ctr);
 #define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
                     candused_c, ccur_c, ccap, d_ctr
 #define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_masks, d_ctr
@@ -737,10 +739,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             HIP_TRY(hipMemcpyAsync(h_ovf, d_ovfc, sizeof h_ovf, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
             uint64_t need_u = 0, need_c = 0;
-            uint32_t max_ovf = 0;
+            uint32_t max_ovf = 0, guard = 0;
             for (uint32_t c = 0; c < n_chunks_p; c++) {
                 need_u = std::max(need_u, h_pc[c]); need_c = std::max(need_c, h_pc[8 + c]);
                 max_ovf = std::max(max_ovf, h_ovf[8 * c]);
+                guard |= h_ovf[8 * c + 2];
             }
             if (getenv("KG_DEBUG"))
                 fprintf(stderr, "[kg] partition attempt %d: %u chunks (largest %llu of %llu blocks), overflow groups <= %u (cap %u), hit list <= %llu "
@@ -749,7 +752,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                         attempt, n_chunks_p, (unsigned long long)max_chunk, (unsigned long long)nblocks, max_ovf, ovf_cap,
                         (unsigned long long)need_u, (unsigned long long)ucap, (unsigned long long)need_c, (unsigned long long)ccap,
                         (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg, (unsigned long long)h_pc[16 + n_chunks_p]);
-            if (max_ovf > ovf_cap) { too_skewed = true; break; }         // more overflow than provisioned: direct path
+            if (guard) { too_skewed = true; st.fallback = 2; break; }    // the scatter pass's spin guard fired: direct path
+            if (max_ovf > ovf_cap) { too_skewed = true; st.fallback = 1; break; }   // more overflow than provisioned: direct path
             n_hits = h_pc[16 + n_chunks_p];
             if (need_u <= ucap && need_c <= ccap) break;
             // a list was too small: now the exact need is known (masks are cleared and everything is redone)
@@ -779,6 +783,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             st.n_hits = (int64_t)n_hits;
             part_done = true;
             st.partitioned = 1;
+            st.part_chunks = (int32_t)n_chunks_p; st.part_buckets = (int32_t)part_buckets; st.part_shift = (int32_t)part_shift;
         }
     }
     if (!part_done) {
@@ -1036,5 +1041,7 @@ const uint8_t *kg_result_container_tail_events(kg_result *r)
 const void *kg_result_device_hits(const kg_result *r) { return r ? r->d_hits : nullptr; }
 const void *kg_result_device_calls(const kg_result *r) { return r ? r->d_calls : nullptr; }
 const void *kg_result_device_otu(const kg_result *r) { return r ? r->d_otu : nullptr; }
+const void *kg_result_device_container_hit_start(const kg_result *r) { return r ? r->d_chs : nullptr; }
+const void *kg_result_device_container_call_start(const kg_result *r) { return r ? r->d_ccs : nullptr; }
 
 }  // extern "C"

@@ -1,17 +1,24 @@
 """Multi-GPU layer: one process per GPU, contigs sharded over ranks, the read-only signature table
-replicated, CALL / OTU-COUNTS records gathered to rank 0 with torch.distributed (backend "nccl" is
+replicated, per-rank record buffers gathered to rank 0 with torch.distributed (backend "nccl" is
 RCCL over xGMI on ROCm; "gloo" for the CPU tests).
 
 The reference has no counterpart (single thread, KGJ = lib/src/kmergutsjava/KmerGutsJava.java);
 the sharding is legal because every sequence is independent: hits depend only on the sequence's
 own k-mers and the table, and the aggregation state is per sequence (KGJ:528, 540).  The exchange
 step is therefore one gather of variable-length record buffers at the end; there is no
-all-reduce.  Hit records (needed only for the -d debug stream) stay sharded in HBM unless
-gather_records is asked for them.
+all-reduce.
+
+The exchange (gather_records): one all_gather of the buffer sizes, then ONE group of point-to-point
+transfers towards rank 0 -- only rank 0 allocates receive buffers (exact sizes, no padding), the
+senders hand over the library's own device buffers (ScanResult.device_view: no host hop on the RCCL
+path).  CALL / OTU records are a few KB and are put back in FASTA order on the host; hit records
+(24 B each, ~110 MB per rank for a 1 Gbp batch on 8 GPUs) stay in HBM: rank 0 scatters every
+rank's records to their final place in the global (container, from0InProt) order with index
+arithmetic on the device -- the per-rank lists are already ordered, so no sort is needed.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -22,6 +29,8 @@ def shard_sequences(lengths: Sequence[int], world_size: int) -> List[np.ndarray]
     """Greedy longest-first balancing of whole sequences over ranks (LPT).  Returns, per rank, the
     ascending list of sequence indices it owns.  Deterministic; ties go to the lowest rank."""
     lengths = np.asarray(lengths, dtype=np.int64)
+    if world_size == 1:
+        return [np.arange(len(lengths), dtype=np.int64)]
     order = np.argsort(-lengths, kind="stable")
     load = np.zeros(world_size, dtype=np.int64)
     owner = np.empty(len(lengths), dtype=np.int64)
@@ -43,26 +52,54 @@ def take_shard(seq: np.ndarray, offsets: np.ndarray, idx: np.ndarray) -> Tuple[n
     return out, off
 
 
-def _gather_var(t: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
-    """Gather 1-D uint8 tensors of different lengths to rank dst (all ranks call)."""
-    world = dist.get_world_size()
-    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(max(sizes), 1)
-    pad = torch.zeros(mx, dtype=torch.uint8, device=t.device)
-    pad[:t.numel()] = t
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)                    # tiny buffers; all_gather exists on every backend
-    if dist.get_rank() != dst:
-        return None
-    return [b[:s] for b, s in zip(bufs, sizes)]
+def _as_u8(x, device) -> torch.Tensor:
+    """numpy array / torch tensor -> contiguous 1-D uint8 tensor on `device` (no copy when it already is one)."""
+    if isinstance(x, torch.Tensor):
+        t = x.contiguous().reshape(-1)
+        if t.dtype != torch.uint8:
+            t = t.view(torch.uint8)
+        return t if t.device == torch.device(device) else t.to(device)
+    a = np.ascontiguousarray(x)
+    t = torch.from_numpy(a.reshape(-1).view(np.uint8).copy() if a.size else np.zeros(0, np.uint8))
+    return t.to(device)
 
 
-def _restore(recs_by_rank, idx_by_rank, n_total_seqs: int, per: int, dtype):
+def gather_buffers(bufs: List[torch.Tensor], dst: int = 0) -> Optional[List[List[torch.Tensor]]]:
+    """Gather K 1-D uint8 buffers of rank-dependent length to rank dst (all ranks call, same K).
+    Returns on dst: out[k][r] = buffer k of rank r (its own buffers are passed through, not copied); None elsewhere.
+    Sizes travel in one all_gather; the payload in one batch of point-to-point transfers, so only dst allocates."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = bufs[0].device
+    mine = torch.tensor([b.numel() for b in bufs], dtype=torch.int64, device=dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    sizes = torch.stack(parts).cpu().tolist()                # [world][K]
+    ops, out = [], None
+    if rank == dst:
+        out = [[None] * world for _ in bufs]
+        for r in range(world):
+            for k, b in enumerate(bufs):
+                if r == dst:
+                    out[k][r] = b
+                else:
+                    out[k][r] = torch.empty(sizes[r][k], dtype=torch.uint8, device=dev)
+                    if sizes[r][k]:
+                        ops.append(dist.P2POp(dist.irecv, out[k][r], r))
+    else:
+        for b in bufs:
+            if b.numel():
+                ops.append(dist.P2POp(dist.isend, b, dst))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()     # the senders' buffers belong to the library: done before they are freed
+    return out
+
+
+def _restore_small(recs_by_rank, idx_by_rank, n_total_seqs: int, per: int, dtype):
     """Concatenate per-rank records (container ids local to the rank's shard, grouped by container in
-    ascending order) into global container order.  Vectorised: no per-sequence Python loop."""
+    ascending order) into global container order.  Host side, for the small record kinds (CALLs)."""
     n_cont = n_total_seqs * per
     gcont, recs = [], []
     for r, rec in enumerate(recs_by_rank):
@@ -83,36 +120,77 @@ def _restore(recs_by_rank, idx_by_rank, n_total_seqs: int, per: int, dtype):
     return rec, starts
 
 
-def gather_records(local: dict, shard_idx: np.ndarray, n_total_seqs: int, per: int, device=None) -> Optional[dict]:
+def restore_hits(hits_by_rank: List[torch.Tensor], chs_by_rank: List[torch.Tensor], idx_by_rank: List[torch.Tensor],
+                 n_total_seqs: int, per: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-rank hit buffers (uint8, 24 B records ordered by local container and position) + their
+    container_hit_start (int64) + the ranks' sequence indices -> (hits int32[n, 6], container_hit_start int64) in
+    global numbering, on the device the buffers are on.  Every record goes straight to its final index:
+        dst = start[global container] + (its index in the rank's list - the rank's start of its local container)."""
+    dev = hits_by_rank[0].device
+    n_cont = n_total_seqs * per
+    counts = torch.zeros(n_cont, dtype=torch.int64, device=dev)
+    ar = torch.arange(per, dtype=torch.int64, device=dev)
+    gmaps = []
+    for chs, idx in zip(chs_by_rank, idx_by_rank):
+        g = (idx[:, None] * per + ar[None, :]).reshape(-1)              # global id of every local container
+        gmaps.append(g)
+        if g.numel():
+            counts[g] = chs[1:] - chs[:-1]
+    starts = torch.zeros(n_cont + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=starts[1:])
+    out = torch.empty((int(starts[-1]), 6), dtype=torch.int32, device=dev)
+    for hb, chs, g in zip(hits_by_rank, chs_by_rank, gmaps):
+        h = hb.view(torch.int32).view(-1, 6)
+        if h.shape[0] == 0:
+            continue
+        lc = h[:, 0].to(torch.int64) & 0xFFFFFFFF
+        gc = g[lc]
+        dst = starts[gc] + (torch.arange(h.shape[0], dtype=torch.int64, device=dev) - chs[lc])
+        out[dst] = h
+        out[dst, 0] = gc.to(torch.int32)                                  # container ids < 2^31 (kg_scan's own limit)
+    return out, starts
+
+
+def gather_records(local: Dict[str, object], shard_idx: np.ndarray, n_total_seqs: int, per: int, device=None) -> Optional[dict]:
     """Gather per-rank results to rank 0 and restore the original sequence order.
 
-    local: {"calls": CALL records, "otu": OTU records (one per local sequence), optional "hits"} as numpy
-    arrays with container ids local to the shard (container // per = local sequence index).
-    Returns on rank 0 {"calls", "container_call_start", "otu" [, "hits", "container_hit_start"]} in global
-    numbering, None elsewhere."""
+    local: {"calls": CALL records, "otu": OTU records (one per local sequence)} and optionally
+    {"hits": hit records, "container_hit_start": int64[n_local_containers + 1]}; numpy arrays or torch tensors
+    (ScanResult.device_view: the library's own HBM buffers), container ids local to the shard
+    (container // per = local sequence index).  "container_hit_start" may be omitted for numpy hit records.
+    Returns on rank 0 {"calls", "container_call_start", "otu"} as numpy arrays [+ "hits" (int32[n, 6] tensor on the
+    exchange device; .cpu().numpy().view(HIT_DTYPE) gives records) and "container_hit_start" (int64 tensor)] in
+    global numbering, None elsewhere."""
     from . import _native as N
-    device = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
-
-    def tobytes(a: np.ndarray) -> torch.Tensor:
-        return torch.from_numpy(np.frombuffer(np.ascontiguousarray(a).tobytes(), dtype=np.uint8).copy()).to(device)
-
-    names = ["calls", "otu"] + (["hits"] if "hits" in local else [])
-    parts = {"idx": _gather_var(tobytes(np.asarray(shard_idx, dtype=np.int64)))}
-    for nm in names:
-        parts[nm] = _gather_var(tobytes(local[nm]))
-    if dist.get_rank() != 0:
+    device = torch.device(device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    with_hits = "hits" in local
+    idx_np = np.ascontiguousarray(np.asarray(shard_idx, dtype=np.int64))
+    bufs = [_as_u8(idx_np, device), _as_u8(local["calls"], device), _as_u8(local["otu"], device)]
+    if with_hits:
+        chs = local.get("container_hit_start")
+        if chs is None:                                  # numpy records: offsets from the (sorted) container column
+            cont = np.asarray(local["hits"]["container"], dtype=np.int64)
+            chs = np.searchsorted(cont, np.arange(len(idx_np) * per + 1))
+        bufs += [_as_u8(local["hits"], device), _as_u8(chs if isinstance(chs, torch.Tensor) else np.asarray(chs, dtype=np.int64), device)]
+    got = gather_buffers(bufs, 0)
+    if got is None:
         return None
-    dt = {"calls": N.CALL_DTYPE, "otu": N.OTU_DTYPE, "hits": N.HIT_DTYPE, "idx": np.dtype("<i8")}
     world = dist.get_world_size()
-    dec = {nm: [np.frombuffer(parts[nm][r].cpu().numpy().tobytes(), dtype=dt[nm]) for r in range(world)] for nm in parts}
+    idx_t = [b.view(torch.int64) for b in got[0]]
+    idx = [t.cpu().numpy() for t in idx_t]
+    calls = [np.frombuffer(b.cpu().numpy().tobytes(), dtype=N.CALL_DTYPE) for b in got[1]]
+    otus = [np.frombuffer(b.cpu().numpy().tobytes(), dtype=N.OTU_DTYPE) for b in got[2]]
     otu = np.zeros(n_total_seqs, dtype=N.OTU_DTYPE)
     seen = np.zeros(n_total_seqs, dtype=np.int64)
     for r in range(world):
-        otu[dec["idx"][r]] = dec["otu"][r]
-        seen[dec["idx"][r]] += 1
+        otu[idx[r]] = otus[r]
+        seen[idx[r]] += 1
     assert (seen == 1).all(), "every sequence must belong to exactly one rank"
     out = {"otu": otu}
-    out["calls"], out["container_call_start"] = _restore(dec["calls"], dec["idx"], n_total_seqs, per, N.CALL_DTYPE)
-    if "hits" in local:
-        out["hits"], out["container_hit_start"] = _restore(dec["hits"], dec["idx"], n_total_seqs, per, N.HIT_DTYPE)
+    out["calls"], out["container_call_start"] = _restore_small(calls, idx, n_total_seqs, per, N.CALL_DTYPE)
+    if with_hits:
+        out["hits"], out["container_hit_start"] = restore_hits(got[3], [b.view(torch.int64) for b in got[4]], idx_t,
+                                                               n_total_seqs, per)
     return out

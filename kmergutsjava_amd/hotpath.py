@@ -33,6 +33,26 @@ class Params:
                           int(self.min_weighted_hits), int(self.max_gap), flags)
 
 
+class _DevMem:
+    """`count` items of `typestr` at a raw HBM address, exposed through __cuda_array_interface__ (version 2)."""
+
+    def __init__(self, ptr: int, count: int, typestr: str, owner):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2,
+                                         "strides": None}
+        self._owner = owner
+
+
+def device_tensor(ptr: int, count: int, typestr: str = "|u1", owner=None, device: Optional[int] = None):
+    """torch tensor over library-owned device memory (no copy).  `owner` is kept alive by the tensor."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    if count == 0 or not ptr:
+        return torch.empty(0, dtype=torch.uint8 if typestr == "|u1" else torch.int64, device=dev)
+    t = torch.as_tensor(_DevMem(ptr, count, typestr, owner), device=dev)
+    t._kg_owner = owner
+    return t
+
+
 class ScanResult:
     """Owns one kg_result.  Record arrays are numpy structured arrays (copies)."""
 
@@ -86,6 +106,53 @@ class ScanResult:
 
     def device_otu_ptr(self) -> int:
         return self._need().kg_result_device_otu(self._h) or 0
+
+    def device_view(self, what: str):
+        """Zero-copy torch view (uint8, or int64 for the two start arrays) of a record array where the library left
+        it in HBM: "hits", "calls", "otu", "container_hit_start", "container_call_start".  Valid until close();
+        plumbing for callers that keep working on the device (RCCL gather, on-device comparisons)."""
+        lib = self._need()
+        st = self.stats
+        n_cont = st["n_containers"]
+        spec = {"hits": (lib.kg_result_device_hits, st["n_hits"] * N.HIT_DTYPE.itemsize, "|u1"),
+                "calls": (lib.kg_result_device_calls, st["n_calls"] * N.CALL_DTYPE.itemsize, "|u1"),
+                "otu": (lib.kg_result_device_otu, st["n_seqs"] * N.OTU_DTYPE.itemsize, "|u1"),
+                "container_hit_start": (lib.kg_result_device_container_hit_start, n_cont + 1, "<i8"),
+                "container_call_start": (lib.kg_result_device_container_call_start, n_cont + 1, "<i8")}[what]
+        return device_tensor(spec[0](self._h) or 0, spec[1], spec[2], owner=self)
+
+    def subset(self, seq_idx, events: bool = False) -> dict:
+        """The records of the sequences seq_idx (ascending indices into the batch), renumbered as if those sequences
+        had been scanned as a batch of their own: legal because every sequence is independent (hits depend on its own
+        k-mers and the table only, the aggregation state is per sequence, KGJ:528, 540).  The hit records are sliced
+        where they are (HBM) and only the slices come to the host."""
+        import torch
+        st = self.stats
+        idx = np.asarray(seq_idx, dtype=np.int64)
+        per = st["n_containers"] // st["n_seqs"] if st["n_seqs"] else 1
+        chs, ccs = self.container_hit_start(), self.container_call_start()
+        cont = (idx[:, None] * per + np.arange(per)[None, :]).reshape(-1)               # old container ids, in order
+        h_n = chs[cont + 1] - chs[cont]
+        c_n = ccs[cont + 1] - ccs[cont]
+        new_chs = np.zeros(len(cont) + 1, dtype=np.int64); np.cumsum(h_n, out=new_chs[1:])
+        new_ccs = np.zeros(len(cont) + 1, dtype=np.int64); np.cumsum(c_n, out=new_ccs[1:])
+        dv = self.device_view("hits").view(torch.int32).view(-1, 6)
+        # the containers of one sequence are adjacent in hits[]: one slice per sequence
+        parts = [dv[int(chs[i * per]):int(chs[i * per + per])] for i in idx]
+        hits = (torch.cat(parts).cpu().numpy() if parts else np.zeros((0, 6), np.int32)).reshape(-1).view(N.HIT_DTYPE).copy()
+        hits["container"] = np.repeat(np.arange(len(cont), dtype=np.uint32), h_n)
+        allc = self.calls()
+        calls = (np.concatenate([allc[int(ccs[i * per]):int(ccs[i * per + per])] for i in idx]) if len(idx)
+                 else np.zeros(0, N.CALL_DTYPE))
+        calls["container"] = np.repeat(np.arange(len(cont), dtype=np.uint32), c_n)
+        out = {"hits": hits, "container_hit_start": new_chs, "calls": calls, "container_call_start": new_ccs,
+               "otu": self.otu()[idx]}
+        if events:
+            ev = self.hit_events()
+            out["hit_events"] = (np.concatenate([ev[int(chs[i * per]):int(chs[i * per + per])] for i in idx]) if len(idx)
+                                 else np.zeros(0, np.uint8))
+            out["container_tail_events"] = self.container_tail_events()[cont]
+        return out
 
     def close(self) -> None:
         if self._h:

@@ -22,6 +22,9 @@ def assert_same_records(gpu, ora, what=""):
     assert gpu.stats["residues"] == ora["residues"], what + " residues"
     import os
     mode = os.environ.get("KG_PARTITION")
+    knobs = os.environ.get("KG_PART_OVF_GROUPS") is not None or os.environ.get("KG_PART_SLACK") is not None
+    if not knobs:       # 1 = overflow beyond the list, 2 = spin guard of the scatter pass: never without a forcing knob
+        assert gpu.stats["fallback"] == 0, "%s: partitioned attempt thrown away (fallback %d)" % (what, gpu.stats["fallback"])
     if mode == "0":
         assert gpu.stats["partitioned"] == 0, what + ": direct strategy requested"
     if mode == "1" and gpu.stats["n_blocks"] > 0 and os.environ.get("KG_PART_OVF_GROUPS") is None and os.environ.get("KG_PART_SLACK") is None and _partition_fits(gpu.stats):
@@ -67,3 +70,26 @@ def plant(seq_bytes: bytes, off, keys, every=40, dna=True, start=10):
             ki += 1
             p += every
     return bytes(s)
+
+
+def chunk_seq_ranges(off, want=4, dna=True, min_chunk_blocks=1 << 20):
+    """The sequence ranges [a, b) of the chunks the partitioned scan cuts a batch into (kmerguts_hip.hip, scan_impl:
+    chunk c starts at the first sequence whose first window block is >= nblocks * c / want; fewer chunks while a
+    chunk would hold fewer than min_chunk_blocks blocks).  A DNA block is 192 forward positions, a protein block
+    64 windows."""
+    L = np.asarray(off[1:] - off[:-1], dtype=np.int64)
+    nb = (np.maximum(L - 23, 0) + 191) // 192 if dna else (np.maximum(L - 8, 0) + 63) // 64
+    ibase = np.zeros(len(L) + 1, dtype=np.int64)
+    np.cumsum(nb, out=ibase[1:])
+    nblocks = int(ibase[-1])
+    while want > 1 and nblocks // want < min_chunk_blocks:
+        want -= 1
+    cuts, clo = [0], [0]
+    for c in range(1, want):
+        k = int(np.searchsorted(ibase, nblocks * c // want, side="left"))
+        cut = int(ibase[k])
+        if clo[-1] < cut < nblocks:
+            clo.append(cut)
+            cuts.append(k)
+    cuts.append(len(L))
+    return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]

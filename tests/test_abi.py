@@ -30,7 +30,22 @@ def test_header_symbols_are_exported(native):
 def test_record_layouts_match_header(native):
     assert native.HIT_DTYPE.itemsize == 24 and native.CALL_DTYPE.itemsize == 24 and native.OTU_DTYPE.itemsize == 44
     assert ctypes.sizeof(native.KgParams) == 24
-    assert ctypes.sizeof(native.KgStats) == 10 * 8 + 4 * 4 + 2 * 4 + 4 * 4
+    assert ctypes.sizeof(native.KgStats) == 10 * 8 + 4 * 4 + 2 * 4 + 3 * 4 + 5 * 4
+
+
+def test_kg_stats_binding_matches_the_c_struct(native, tmp_path):
+    """Every field of the ctypes KgStats sits where gcc puts it for include/kmerguts_hip.h."""
+    import subprocess
+    fields = [f for f, _ in native.KgStats._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "kmerguts_hip.h"\nint main(void){\n' +
+                   'printf("%zu\\n", sizeof(kg_stats));\n' +
+                   "".join('printf("%%zu\\n", offsetof(kg_stats, %s));\n' % f for f in fields) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(native.KgStats)
+    assert out[1:] == [getattr(native.KgStats, f).offset for f in fields]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -39,16 +39,27 @@ def _worker(rank, world, port, dna, tmp):
         mine = shards[rank]
         s_seq, s_off = kd.take_shard(sb, off, mine)
         loc = kgo.run(img, s_seq, s_off, aa=not dna, lookup_mode=1)
-        local = {k: loc[k] for k in ("calls", "otu", "hits")}
-        got = kd.gather_records(local, mine, len(lens), per, device="cpu")
+        # records as numpy arrays (offsets derived) and as torch tensors with the offsets handed over, the form
+        # ScanResult.device_view gives on the RCCL path
+        as_np = {k: loc[k] for k in ("calls", "otu", "hits")}
+        as_t = {k: torch.from_numpy(loc[k].view(np.uint8).copy()) for k in ("calls", "otu", "hits")}
+        as_t["container_hit_start"] = torch.from_numpy(loc["container_hit_start"].copy())
+        for local in (as_np, as_t, {k: loc[k] for k in ("calls", "otu")}):
+            got = kd.gather_records(local, mine, len(lens), per, device="cpu")
+            if rank == 0:
+                whole = kgo.run(img, sb, off, aa=not dna, lookup_mode=1)
+                for k in ("calls", "container_call_start", "otu"):
+                    assert got[k].tobytes() == whole[k].tobytes(), k
+                if "hits" in local:
+                    assert got["hits"].numpy().tobytes() == whole["hits"].tobytes()
+                    assert np.array_equal(got["container_hit_start"].numpy(), whole["container_hit_start"])
+                else:
+                    assert "hits" not in got
+                assert len(whole["calls"]) > 5 and len(whole["hits"]) > 100
+            else:
+                assert got is None
         if rank == 0:
-            whole = kgo.run(img, sb, off, aa=not dna, lookup_mode=1)
-            for k in ("calls", "container_call_start", "otu", "hits", "container_hit_start"):
-                assert got[k].tobytes() == whole[k].tobytes(), k
-            assert len(whole["calls"]) > 5
             open(os.path.join(tmp, "ok"), "w").write("ok")
-        else:
-            assert got is None
     finally:
         dist.destroy_process_group()
 

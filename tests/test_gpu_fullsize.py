@@ -1,0 +1,186 @@
+"""BASELINE-size configurations through the C ABI on the MI355X: the production geometry of the partitioned scan
+(33.6 GB table, 2^21-slot buckets, 668 of them, chunks of whole contigs on three streams) is reached only at these
+sizes.  The oracle cannot finish 1 Gbp in seconds, so parity is proven in three ways:
+
+  * the two scan strategies (direct probing / partitioned probing: different kernels, different orderings of the
+    work) must leave byte-identical hit, CALL and OTU records and container offsets in HBM -- compared on the device;
+  * the oracle (literal sorted merge-join, lookup_mode 0) scans a sub-batch of whole contigs drawn from EVERY chunk of
+    the pipeline (sequences are independent, KGJ:528, 540) and those containers' records must be byte-identical;
+  * size-independent properties of the whole result: hits strictly ascending in (container, from0InProt),
+    container_hit_start consistent with the records, the oracle's own counters reproduced on the sample.
+
+PARITY STATUS of the oracle itself: unpinned (oracle/kg_oracle.h) -- the reference holds no input -> output pair.
+"""
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import chunk_seq_ranges
+
+pytestmark = pytest.mark.gpu
+
+NUM_SIGS = 1_400_303_159          # BASELINE.md section 4 / SURVEY 8d: the full-size table, 33.6 GB at load 0.5
+
+
+@pytest.fixture(scope="module")
+def hp():
+    from kmergutsjava_amd import hotpath
+    return hotpath
+
+
+@pytest.fixture(scope="module")
+def full_table(hp):
+    """The 1 400 303 159-slot table, built in HBM (seed 202, as bench.py), plus a lazily made host image for the oracle."""
+    from kmergutsjava_amd import synth
+    dev = torch.device("cuda", 0)
+    rec, placed, keys = synth.random_table(NUM_SIGS, 0.5, 202, dev)
+    del keys
+    torch.cuda.synchronize()
+    tab = hp.SignatureTable.from_device_ptr(rec.data_ptr(), NUM_SIGS, 0, keepalive=rec)
+    assert tab.info()["occupied"] == placed
+    box = {"tab": tab, "rec": rec, "img": None}
+
+    def image():
+        if box["img"] is None:
+            host = torch.empty(24 + NUM_SIGS * 24, dtype=torch.uint8)
+            host[:24] = torch.frombuffer(bytearray(struct.pack("<qqq", NUM_SIGS, 24, 1)), dtype=torch.uint8)
+            host[24:].view(torch.int32).view(NUM_SIGS, 6).copy_(rec)
+            box["img"] = host.numpy()
+        return box["img"]
+
+    box["image"] = image
+    yield box
+    tab.close()
+    box["img"] = None
+    del rec
+    torch.cuda.empty_cache()
+
+
+def _same_on_device(a, b, what):
+    for name in ("hits", "calls", "otu", "container_hit_start", "container_call_start"):
+        x, y = a.device_view(name), b.device_view(name)
+        assert x.shape == y.shape, "%s: %s sizes differ (%s vs %s)" % (what, name, tuple(x.shape), tuple(y.shape))
+        assert torch.equal(x, y), "%s: %s differ between the strategies" % (what, name)
+    for k in ("n_hits", "n_calls", "residues", "windows"):
+        assert a.stats[k] == b.stats[k], (what, k)
+
+
+def _whole_result_properties(r, per):
+    """hits[] ordered by (container, from0InProt), positions unique per container, offsets consistent."""
+    n = r.stats["n_hits"]
+    h = r.device_view("hits").view(torch.int32).view(-1, 6)
+    cont = h[:, 0].to(torch.int64) & 0xFFFFFFFF
+    key = (cont << 32) | (h[:, 1].to(torch.int64) & 0xFFFFFFFF)
+    assert int(h[:, 1].min()) >= 0
+    assert bool((key[1:] > key[:-1]).all()), "hits not strictly ascending in (container, from0InProt)"
+    chs = r.device_view("container_hit_start")
+    n_cont = r.stats["n_containers"]
+    assert int(chs[0]) == 0 and int(chs[-1]) == n
+    want = torch.searchsorted(cont.contiguous(), torch.arange(n_cont + 1, dtype=torch.int64, device=cont.device))
+    assert torch.equal(chs, want), "container_hit_start does not match the records"
+    ccs = r.device_view("container_call_start")
+    assert int(ccs[0]) == 0 and int(ccs[-1]) == r.stats["n_calls"] and bool((ccs[1:] >= ccs[:-1]).all())
+    assert n_cont == r.stats["n_seqs"] * per
+
+
+def _oracle_sample(oracle, image, seq, off, idx, r, what, **kw):
+    """The oracle on the sub-batch idx (literal merge-join) against the same containers of the full-size result."""
+    sub_off = np.zeros(len(idx) + 1, dtype=np.int64)
+    np.cumsum((off[1:] - off[:-1])[idx], out=sub_off[1:])
+    sub = torch.cat([seq[int(off[i]):int(off[i + 1])] for i in idx]).cpu().numpy()
+    ora = oracle.run(image, sub, sub_off, lookup_mode=0, **kw)
+    got = r.subset(idx, events=True)
+    for name in ("hits", "calls", "otu", "hit_events", "container_tail_events"):
+        assert got[name].tobytes() == ora[name].tobytes(), "%s: %s of the sampled contigs differ from the oracle" % (what, name)
+    assert np.array_equal(got["container_hit_start"], ora["container_hit_start"]), what
+    assert np.array_equal(got["container_call_start"], ora["container_call_start"]), what
+    return ora
+
+
+def test_config3_1gbp_contig_mix_full_table(hp, oracle, full_table, monkeypatch):
+    """BASELINE config 3 exactly as bench.py runs it: 1 Gbp contig mix vs the 33.6 GB table, default environment."""
+    from kmergutsjava_amd import synth
+    dev = torch.device("cuda", 0)
+    tab = full_table["tab"]
+    lens = synth.contig_mix_lengths(1_000_000_000, 301)
+    off = synth.offsets_of(lens)
+    seq = synth.random_dna(int(off[-1]), 302, dev)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("KG_PARTITION", raising=False)
+    with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as rp:
+        st = rp.stats
+        assert st["partitioned"] == 1 and st["fallback"] == 0 and st["scan_launches"] >= 1
+        assert st["part_chunks"] == 4 and st["part_shift"] == 21 and st["part_buckets"] == 668, st
+        _whole_result_properties(rp, 6)
+        # contigs from every one of the four chunks
+        idx = synth.spread_sample(off, groups=4, per_group=20, max_bp_per_group=2_500_000)
+        ranges = chunk_seq_ranges(off, 4)
+        per_chunk = [int(((idx >= a) & (idx < b)).sum()) for a, b in ranges]
+        assert len(ranges) == 4 and min(per_chunk) >= 3, (ranges, per_chunk)
+        ora = _oracle_sample(oracle, full_table["image"](), seq, off, idx, rp, "config 3 partitioned")
+        assert len(ora["hits"]) > 100_000
+        # the instrumented kernels (KG_F_COUNTERS) and the other strategy: identical records on the device
+        with tab.scan(None, off, hp.Params(counters=True), device_ptr=seq.data_ptr()) as rc:
+            assert rc.stats["partitioned"] == 1 and rc.stats["fallback"] == 0
+            _same_on_device(rp, rc, "config 3 partitioned vs partitioned+counters")
+            wv, si = rc.stats["windows_valid"], rc.stats["slots_inspected"]
+        monkeypatch.setenv("KG_PARTITION", "0")
+        with tab.scan(None, off, hp.Params(counters=True), device_ptr=seq.data_ptr()) as rd:
+            assert rd.stats["partitioned"] == 0 and rd.stats["fallback"] == 0
+            _same_on_device(rp, rd, "config 3 partitioned vs direct")
+            assert rd.stats["windows_valid"] == wv and rd.stats["slots_inspected"] == si
+        # the same counters from the oracle on the sample (direct-probe mode counts slots; merge-join mode does not)
+        sub_off = np.zeros(len(idx) + 1, dtype=np.int64)
+        np.cumsum((off[1:] - off[:-1])[idx], out=sub_off[1:])
+        sub = torch.cat([seq[int(off[i]):int(off[i + 1])] for i in idx])
+        o1 = oracle.run(full_table["image"](), sub.cpu().numpy(), sub_off, lookup_mode=1)
+        monkeypatch.delenv("KG_PARTITION", raising=False)
+        with tab.scan(None, sub_off, hp.Params(counters=True), device_ptr=sub.data_ptr()) as rs:
+            assert rs.stats["windows_valid"] == o1["windows_valid"] and rs.stats["slots_inspected"] == o1["slots_inspected"]
+            assert rs.hits().tobytes() == o1["hits"].tobytes() == ora["hits"].tobytes()
+
+
+def test_config2_100mbp_uniform_full_table(hp, oracle, full_table, monkeypatch):
+    """BASELINE config 2: 1000 x 100 kbp uniform DNA vs the full table (partitioned by default, one or two chunks)."""
+    from kmergutsjava_amd import synth
+    dev = torch.device("cuda", 0)
+    tab = full_table["tab"]
+    seq, off = synth.dna_uniform_config(1000, 100_000, 201, dev)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("KG_PARTITION", raising=False)
+    with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as rp:
+        assert rp.stats["partitioned"] == 1 and rp.stats["fallback"] == 0, rp.stats
+        _whole_result_properties(rp, 6)
+        idx = synth.spread_sample(off, groups=max(4, rp.stats["part_chunks"]), per_group=5)
+        _oracle_sample(oracle, full_table["image"](), seq, off, idx, rp, "config 2")
+        monkeypatch.setenv("KG_PARTITION", "0")
+        with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as rd:
+            assert rd.stats["partitioned"] == 0
+            _same_on_device(rp, rd, "config 2 partitioned vs direct")
+
+
+@pytest.mark.parametrize("dna", [True, False])
+def test_config5_high_density_full_size(hp, oracle, dna, monkeypatch):
+    """BASELINE config 5: 100 Mbp (DNA) / 10 k proteins assembled from signature k-mers of <= 32 functions, <= 8 OTUs."""
+    from kmergutsjava_amd import synth
+    dev = torch.device("cuda", 0)
+    n_contigs, kpc = (1000, 4167) if dna else (10000, 38)
+    seq, off, rec = synth.high_density_device(n_contigs, kpc, 20_000_003, 8_000_000, 501, dna, dev)
+    torch.cuda.synchronize()
+    img = synth.table_image(rec)
+    per = 6 if dna else 1
+    monkeypatch.delenv("KG_PARTITION", raising=False)
+    with hp.SignatureTable.from_device_ptr(rec.data_ptr(), 20_000_003, 0, keepalive=rec) as tab:
+        with tab.scan(None, off, hp.Params(aa=not dna), device_ptr=seq.data_ptr()) as ra:
+            assert ra.stats["fallback"] == 0
+            _whole_result_properties(ra, per)
+            assert ra.stats["n_calls"] > (100_000 if dna else 5_000) and ra.stats["n_hits"] > 10 * ra.stats["n_calls"]
+            idx = synth.spread_sample(off, groups=4, per_group=10 if dna else 500, max_bp_per_group=1_000_000)
+            ora = _oracle_sample(oracle, img, seq, off, idx, ra, "config 5 dna=%s" % dna, aa=not dna)
+            assert len(ora["calls"]) > 100
+            monkeypatch.setenv("KG_PARTITION", "0" if ra.stats["partitioned"] else "1")
+            with tab.scan(None, off, hp.Params(aa=not dna), device_ptr=seq.data_ptr()) as rb:
+                assert rb.stats["partitioned"] != ra.stats["partitioned"] and rb.stats["fallback"] == 0, rb.stats
+                _same_on_device(ra, rb, "config 5 dna=%s, the two strategies" % dna)

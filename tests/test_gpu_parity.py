@@ -376,6 +376,10 @@ def test_skewed_repeats_overflow_and_fallback(hp, oracle, monkeypatch, strategy)
                 assert_same_records(r, ora, "skew %s %s" % (strategy, env))
                 assert r.stats["windows_valid"] == ora["windows_valid"]
                 assert r.stats["slots_inspected"] == ora["slots_inspected"]
+                if "KG_PART_OVF_GROUPS" in env:      # three overflow groups cannot hold a homopolymer run: thrown away, visibly
+                    assert r.stats["partitioned"] == 0 and r.stats["fallback"] == 1, r.stats
+                elif strategy == "partitioned":
+                    assert r.stats["partitioned"] == 1 and r.stats["fallback"] == 0, r.stats
 
 
 def test_partitioned_chunk_pipeline(hp, oracle, monkeypatch):
