@@ -117,7 +117,10 @@ typedef struct kg_stats {
     int32_t part_chunks;         /* partitioned only: chunks of whole sequences the batch was cut into            */
     int32_t part_buckets;        /* partitioned only: slot-range buckets (each 2^part_shift slots)                */
     int32_t part_shift;
-    int32_t reserved;
+    int32_t lookup_ran_off;      /* 1: some query walked to the end of the record stream undecided -- where the     */
+                                 /* reference's table stream throws EOFException and its lookup ends with            */
+                                 /* "Error: null" instead of "Kmers found: ..." (KGJ:799-802, 1031-1033, 1097-1126); */
+                                 /* the records are the same either way (EOF == not found)                           */
 } kg_stats;
 
 typedef struct kg_table  kg_table;

@@ -470,11 +470,14 @@ __device__ __forceinline__ void row_record_key(const BlockDesc &bd, int r, int l
 // k-mer, an empty slot or the end of the stream; never wrap).  16 tags per load, records touched only on a
 // fingerprint match; the rare longer walks share one copy of the generic walk, rows picked by register muxes.
 // On return bit q of the result is set iff query q was found, with ent[q] = the record's payload.
+// ran_off is set when a walk reaches the end of the record stream undecided: the point at which the reference's
+// table stream throws EOFException and its lookup ends with "Error: null" instead of "Kmers found" (KGJ:799-802,
+// 1097-1126); the records are the same either way (EOF == not found).
 // val[q] = the k-mer value (compared with the record keys), home_in[q] / fp[q] = its home slot and fingerprint.
 template <int N, bool COUNTERS>
 __device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t (&val)[N], const uint64_t (&home_in)[N],
                                             const uint32_t (&fp)[N], bool (&valid)[N], Payload (&ent)[N],
-                                            unsigned long long &ctr_valid, unsigned long long &ctr_slots)
+                                            unsigned long long &ctr_valid, unsigned long long &ctr_slots, bool &ran_off)
 {
     uint64_t cand[N];     // slot under examination
     uint32_t skip[N];
@@ -484,6 +487,7 @@ __device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t
     for (int q = 0; q < N; q++) {
         cand[q] = home_in[q];
         if (COUNTERS) { home[q] = cand[q]; if (valid[q]) ctr_valid++; }   // query k-mers (KGJ:913-920)
+        if (valid[q] && cand[q] >= tab.limit) ran_off = true;
         valid[q] = valid[q] && cand[q] < tab.limit;     // beyond the stream: EOF, not found, nothing inspected
         cand[q] = probe_window(cand[q], &skip[q]);
         if (valid[q]) tg[q] = load_tags(tab.tags + cand[q]);
@@ -502,6 +506,7 @@ __device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t
                 cand[q] += (uint64_t)i;
                 if (COUNTERS) stop[q] = cand[q];
                 if (!emp) st1 |= 1u << q;
+                else if (cand[q] >= tab.limit) ran_off = true;      // the "empty slot" is the padding behind the last record
             }
         }
     }
@@ -531,13 +536,13 @@ __device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t
             bool done = false, hit = false;
             Entry e;
             e.key = 0; e.oI = e.avg = e.fI = 0; e.wt = 0.f;
-            if (s >= tab.limit) { done = true; s = tab.limit; }
+            if (s >= tab.limit) { done = true; s = tab.limit; ran_off = true; }
             else {
                 Tags16 x = load_tags(tab.tags + s);
                 bool emp;
                 int i = first_stop(x, f, &emp);
                 if (i == 16) s += 16;
-                else if (emp) { done = true; s += (uint64_t)i; }
+                else if (emp) { done = true; s += (uint64_t)i; if (s >= tab.limit) ran_off = true; }
                 else {
                     s += (uint64_t)i;
                     e = load_entry(tab, s);
@@ -568,6 +573,12 @@ __device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t
         }
     }
     return foundm;
+}
+
+// ctr[3]: sticky "a probe walked off the end of the record stream" (kg_stats.lookup_ran_off)
+__device__ __forceinline__ void flush_ran_off(bool ran_off, unsigned long long *ctr, int lane)
+{
+    if (__ballot(ran_off) && lane == 0) atomicOr(&ctr[3], 1ull);
 }
 
 // wave reduction of the two counters, one atomic pair per wave
@@ -622,6 +633,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
     __syncthreads();
 
     unsigned long long ctr_valid = 0, ctr_slots = 0;
+    bool ran_off = false;
     unsigned long long res_at = 0, res_end = 0;          // this wave's staging reservation (uniform)
 
     for (uint32_t it_v = wave_global; it_v < n_blocks; it_v += n_waves) {
@@ -644,7 +656,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
             }
 
             Payload ent[RPG];
-            const uint32_t foundm = probe_n<RPG, COUNTERS>(tab, val, home, fp, valid, ent, ctr_valid, ctr_slots);
+            const uint32_t foundm = probe_n<RPG, COUNTERS>(tab, val, home, fp, valid, ent, ctr_valid, ctr_slots, ran_off);
 
             // ---- ordered compaction: ballot per row, staging records handed out from the wave's reservation
             uint32_t cnt[RPG], rank[RPG];
@@ -690,6 +702,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
     }
 
     if (COUNTERS) flush_counters(ctr_valid, ctr_slots, ctr, lane);
+    flush_ran_off(ran_off, ctr, lane);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     };
 
     unsigned long long n_valid = 0;
+    bool ran_off = false;
     const uint32_t n_iter = (n_blocks + n_wg * kScatterWaves - 1) / (n_wg * kScatterWaves);
     // the next block's descriptor and characters are fetched while the current block is encoded
     BlockDesc bd_next;
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 bool valid = row_halves<AA>(l, r, lane, bd, &hi, &lo);
                 const uint32_t slot = split_fast(hi, lo, num_sigs, m35, &q);
                 if (valid) { n_valid++; n_valid_block++; }              // query k-mers (KGJ:913-920)
+                if (valid && slot >= limit32) ran_off = true;           // (truncated table file)
                 valid = valid && slot < limit32;                        // beyond the stream: never probed
                 bk[r] = slot >> shift;
                 const uint32_t low = (q << shift) | (slot & ((1u << shift) - 1u));
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) fill[(uint64_t)b * n_wg + w] = wrel[b];
     for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
     if (lane == 0 && n_valid) atomicAdd(&ctr[0], n_valid);
+    flush_ran_off(ran_off, ctr, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -333,6 +336,7 @@ __global__ __launch_bounds__(256) void lowc_blocks_kernel(
     __syncthreads();
     const uint32_t limit32 = limit < 0xFFFFFFFFull ? (uint32_t)limit : 0xFFFFFFFFu;
     unsigned long long n_valid = 0;
+    bool ran_off = false;
     // Overflow groups come from a wave-private pool reserved 32 at a time: one returning atomic on the list's cursor
     // per set would run at the ~90 per microsecond a single word sustains.  Unused pool groups are handed in empty.
     uint32_t pool_at = 0, pool_end = 0;                             // wave-uniform
@@ -369,6 +373,7 @@ __global__ __launch_bounds__(256) void lowc_blocks_kernel(
             bool valid = row_halves<AA>(l, r, lane, bd, &hi, &lo);
             const uint32_t slot = split_fast(hi, lo, num_sigs, m35, &q);
             if (valid) n_valid++;
+            if (valid && slot >= limit32) ran_off = true;
             bool pend = valid && slot < limit32;
             const uint32_t bkt = slot >> shift;
             const uint64_t e = ((uint64_t)((it << 9) | ((uint32_t)r << 6) | (uint32_t)lane) << 32) | ((q << shift) | (slot & ((1u << shift) - 1u)));
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(256) void lowc_blocks_kernel(
     pool_flush();
     for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
     if (lane == 0 && n_valid) atomicAdd(&ctr[0], n_valid);
+    flush_ran_off(ran_off, ctr, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -443,7 +449,7 @@ __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, 
                                               kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used,
                                               unsigned long long *cursor, uint64_t ulist_cap,
                                               unsigned long long *__restrict__ masks, UListState &u,
-                                              unsigned long long &ctr_slots, int lane)
+                                              unsigned long long &ctr_slots, bool &ran_off, int lane)
 {
     constexpr uint32_t ROWS = AA ? 1 : 6;
     uint64_t val[N], slot[N];
@@ -460,7 +466,7 @@ __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, 
     }
     Payload pay[N];
     unsigned long long ctr_dummy = 0;
-    const uint32_t foundm = probe_n<N, COUNTERS>(tab, val, slot, fp, valid, pay, ctr_dummy, ctr_slots);
+    const uint32_t foundm = probe_n<N, COUNTERS>(tab, val, slot, fp, valid, pay, ctr_dummy, ctr_slots, ran_off);
     uint32_t cnt[N], rank[N], total = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -547,6 +553,7 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
     __shared__ uint32_t s_region;
     const int lane = threadIdx.x & 63;
     unsigned long long ctr_slots = 0;
+    bool ran_off = false;
     UListState u;
     u.base = 0; u.used = kUChunk; u.have = false;      // "full": the first append takes a chunk
 
@@ -602,7 +609,10 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                         cur[k] += (uint64_t)i;
                         if (i == 16) { candm |= 1u << k; walkm |= 1u << k; }
                         else if (!emp) candm |= 1u << k;
-                        else if (COUNTERS) ctr_slots += (cur[k] < limit ? cur[k] + 1 : limit) - home[k];
+                        else {
+                            if (cur[k] >= limit) ran_off = true;   // the "empty slot" is the padding behind the last record
+                            if (COUNTERS) ctr_slots += (cur[k] < limit ? cur[k] + 1 : limit) - home[k];
+                        }
                     }
                 }
                 // candidates -> list
@@ -633,6 +643,7 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
         }
     }
     chunk_finish(u, cand_used, cand_cap, lane);
+    flush_ran_off(ran_off, ctr, lane);
     if (COUNTERS) {
         for (int off = 32; off > 0; off >>= 1) ctr_slots += __shfl_down(ctr_slots, off);
         if (lane == 0) atomicAdd(&ctr[1], ctr_slots);
@@ -656,6 +667,7 @@ __global__ __launch_bounds__(256) void verify_kernel(
     const unsigned long long cur = *cand_cursor;
     const uint32_t n_chunks = (uint32_t)((cur < cand_cap ? cur : cand_cap) / kUChunk);
     unsigned long long ctr_slots = 0;
+    bool ran_off = false;
     UListState u;
     u.base = 0; u.used = kUChunk; u.have = false;
     for (uint32_t c = wave_global; c < n_chunks; c += n_waves) {
@@ -680,13 +692,13 @@ __global__ __launch_bounds__(256) void verify_kernel(
                 if (!found) {
                     const uint32_t f = tag_qs(quo, home);
                     for (;;) {
-                        if (s >= limit) { s = limit; break; }
+                        if (s >= limit) { s = limit; ran_off = true; break; }
                         const Tags16 x = load_tags(tab.tags + s);
                         bool emp;
                         const int i = first_stop(x, f, &emp);
                         if (i == 16) { s += 16; continue; }
                         s += (uint64_t)i;
-                        if (emp) break;
+                        if (emp) { if (s >= limit) ran_off = true; break; }
                         e = load_entry(tab, s);
                         if (e.key == (int64_t)r.val) { found = true; break; }
                         s += 1;
@@ -710,6 +722,7 @@ __global__ __launch_bounds__(256) void verify_kernel(
         }
     }
     chunk_finish(u, chunk_used, ulist_cap, lane);
+    flush_ran_off(ran_off, ctr, lane);
     if (COUNTERS) {
         for (int off = 32; off > 0; off >>= 1) ctr_slots += __shfl_down(ctr_slots, off);
         if (lane == 0) atomicAdd(&ctr[1], ctr_slots);
@@ -730,6 +743,7 @@ __global__ __launch_bounds__(256) void overflow_probe_kernel(
     TableView tab;
     tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic; tab.m35 = 0;
     unsigned long long ctr_slots = 0;
+    bool ran_off = false;
     UListState u;
     u.base = 0; u.used = kUChunk; u.have = false;
     const uint32_t n_groups = min(*ovf_cursor, ovf_cap);
@@ -737,9 +751,10 @@ __global__ __launch_bounds__(256) void overflow_probe_kernel(
         const uint32_t b = ovf_bucket[g];
         uint64_t e[1];
         e[0] = lane < (int)kGroup ? ovf_ent[(uint64_t)g * kGroup + lane] : kEntInvalid;
-        probe_entries<AA, 1, COUNTERS>(tab, b, shift, e, ulist, chunk_used, cursor, ulist_cap, masks, u, ctr_slots, lane);
+        probe_entries<AA, 1, COUNTERS>(tab, b, shift, e, ulist, chunk_used, cursor, ulist_cap, masks, u, ctr_slots, ran_off, lane);
     }
     if (lane == 0 && u.have && u.base + kUChunk <= ulist_cap) chunk_used[u.base / kUChunk] = u.used;
+    flush_ran_off(ran_off, ctr, lane);
     if (COUNTERS) {
         for (int off = 32; off > 0; off >>= 1) ctr_slots += __shfl_down(ctr_slots, off);
         if (lane == 0) atomicAdd(&ctr[1], ctr_slots);

@@ -22,6 +22,7 @@
 #include <chrono>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/kmerguts_hip.h"
@@ -276,6 +277,33 @@ long long now_ms()
 
 }  // namespace
 
+// encodedKmer (KGJ:274-292) of the window behind a hit record: container f of a sequence (protein: f = 0; DNA: + 0 1 2,
+// - 0 1 2, KGJ:1064-1072), residue index pos.  Host side, for the -d line "Kmers found" only.
+static int64_t kmer_value_at(const uint8_t *s, int64_t len, bool aa, int f, int32_t pos)
+{
+    static const char *alpha = "ACDEFGHIKLMNPQRSTVWY";
+    static const char *code = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
+    auto aa_of = [&](char c) -> int64_t { const char *q = strchr(alpha, c); return (q && c) ? q - alpha : 20; };
+    auto base = [](uint8_t c) -> int { switch (c) { case 'a': case 'A': return 0; case 'c': case 'C': return 1;
+                                                     case 'g': case 'G': return 2; case 't': case 'T': case 'u': case 'U': return 3;
+                                                     default: return 4; } };
+    int64_t v = 0;
+    for (int j = 0; j < 8; j++) {
+        int64_t c;
+        if (aa) c = aa_of((char)s[pos + j]);
+        else {
+            int b[3];
+            for (int t = 0; t < 3; t++) {
+                const int64_t k = (f % 3) + 3 * ((int64_t)pos + j) + t;             // base index on the window's strand
+                b[t] = f < 3 ? base(s[k]) : 3 - base(s[len - 1 - k]);                // revComp (KGJ:263-272)
+            }
+            c = (b[0] | b[1] | b[2]) > 3 || b[0] < 0 || b[1] < 0 || b[2] < 0 ? 20 : aa_of(code[b[0] * 16 + b[1] * 4 + b[2]]);
+        }
+        v = v * 20 + c;
+    }
+    return v;
+}
+
 int main(int argc, char **argv)
 {
     Options o;
@@ -290,8 +318,11 @@ int main(int argc, char **argv)
             if (o.debug) out.put(m + "\n");
             if (!to_stdout) printf("%s\n", m.c_str());
         };
-        const char *tmp = getenv("TMPDIR");
-        info(std::string("Temp. directory: ") + (tmp ? tmp : "/tmp"));
+        {   // KGJ:108, 744-748: the canonical path of java.io.tmpdir, which is /tmp on Linux whatever $TMPDIR says
+            char *canon = realpath("/tmp", nullptr);
+            info(std::string("Temp. directory: ") + (canon ? canon : "/tmp"));
+            free(canon);
+        }
 
         std::string table = o.dir + "/kmer.table.mem_map", fidx = o.dir + "/function.index";
         if (exists(table + ".gz")) table += ".gz";                 // KGJ:750-753
@@ -332,11 +363,52 @@ int main(int argc, char **argv)
             out.put("Kmer-table info: numSigs=" + std::to_string(ns) + ", entrySize=" + std::to_string(es) +
                     ", version=" + std::to_string(ver) + "\n");
         }
+        bool error_reported = false;
         kg_params p{};
         p.aa = o.aa; p.order_constraint = o.order_constraint; p.min_hits = o.min_hits;
         p.min_weighted_hits = o.min_weighted_hits; p.max_gap = o.max_gap; p.flags = 0;
         const int per = o.aa ? 1 : 6;
         const int64_t kMaxBatchChars = 1500000000ll;               // below the ABI's 2^32-256 windows per call
+        if (o.debug) {
+            // KGJ:1031-1033 "Kmers found: N (pos-count=M)": N = distinct matched k-mer values, M = hit records, over
+            // EVERY FASTA record (the reference's lookup fills the containers of records that a later record of the
+            // same id shadows in the report too, KGJ:805-809).  The line precedes the report, so -d scans the records
+            // once more here, hit records only; a hit record does not carry its k-mer: recomputed from the characters.
+            kg_params pc = p;
+            pc.flags = KG_F_SKIP_AGGREGATE;
+            std::unordered_set<int64_t> distinct;
+            long long pos_count = 0;
+            bool ran_off = false;
+            int64_t a = 0;
+            while (a < n) {
+                int64_t b = a;
+                while (b < n && (b == a || fa.off[(size_t)b + 1] - fa.off[(size_t)a] <= kMaxBatchChars)) b++;
+                std::vector<int64_t> boff((size_t)(b - a) + 1);
+                for (int64_t k = a; k <= b; k++) boff[(size_t)(k - a)] = fa.off[(size_t)k] - fa.off[(size_t)a];
+                kg_result *res = nullptr;
+                check(kg_scan(tab, &pc, fa.seq.data() + fa.off[(size_t)a], boff.data(), b - a, &res));
+                const kg_hit *hits = kg_result_hits(res);
+                const int64_t *chs = kg_result_container_hit_start(res);
+                if (!hits || !chs) die(std::string("libkmerguts_hip: ") + kg_last_error());
+                kg_stats stc;
+                check(kg_result_stats(res, &stc));
+                ran_off = ran_off || stc.lookup_ran_off;
+                for (int64_t k = a; k < b; k++)
+                    for (int f = 0; f < per; f++) {
+                        const int64_t cont = (k - a) * per + f;
+                        for (int64_t i = chs[cont]; i < chs[cont + 1]; i++)
+                            distinct.insert(kmer_value_at(fa.seq.data() + fa.off[(size_t)k], fa.off[(size_t)k + 1] - fa.off[(size_t)k],
+                                                          o.aa, f, hits[i].from0InProt));
+                        pos_count += chs[cont + 1] - chs[cont];
+                    }
+                kg_result_free(res);
+                a = b;
+            }
+            // a query that walks off the end of the table makes the reference's stream throw EOFException: run() prints
+            // "Error: null" and carries on, "Kmers found" is not reached (KGJ:797-802)
+            if (ran_off) { info("Error: null"); error_reported = true; }
+            else out.put("Kmers found: " + std::to_string(distinct.size()) + " (pos-count=" + std::to_string(pos_count) + ")\n");
+        }
         long long t_group = 0;
         size_t at = 0;
         char num[64];
@@ -376,6 +448,11 @@ int main(int argc, char **argv)
                 if (!hits || !chs || !ev || !tail) die(std::string("libkmerguts_hip: ") + kg_last_error());
             }
             // with one batch (inputs up to ~1.5 Gbp) the info lines sit exactly where the reference prints them
+            if (!error_reported) {
+                kg_stats stb;
+                check(kg_result_stats(res, &stb));
+                if (stb.lookup_ran_off) { info("Error: null"); error_reported = true; }    // KGJ:797-802
+            }
             if (at == 0) info("Lookup time: " + std::to_string(now_ms() - t2) + " ms.");
             long long t3 = now_ms();
             for (size_t j = 0; j < end - at; j++) {

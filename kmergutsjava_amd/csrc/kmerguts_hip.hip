@@ -520,7 +520,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
 
     kg::BlockDesc *d_blocks = nullptr;
     uint32_t *d_counts = nullptr, *d_offs = nullptr, *d_bsb = nullptr;
-    uint64_t *d_partial = nullptr, *d_totals = nullptr;   // totals[0] hits, [1] cursor, [2] ctr_valid, [3] ctr_slots, [4] calls
+    uint64_t *d_partial = nullptr, *d_totals = nullptr;   // totals[0] hits, [1] cursor, [2] ctr_valid, [3] ctr_slots, [4] calls, [5] ran off (sticky)
     if ((rc = sc.get(&d_blocks, nblocks))) return rc;
     if ((rc = sc.get(&d_counts, n_rows))) return rc;
     if ((rc = sc.get(&d_offs, n_rows))) return rc;
@@ -771,11 +771,12 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             res->d_hits = nullptr;
         } else {
             HIP_TRY(hipEventRecord(t->ev[2], t->stream));
-            uint64_t h_tot[4] = {0, 0, 0, 0};
-            HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 32, hipMemcpyDeviceToHost, t->stream));
+            uint64_t h_tot[6] = {0, 0, 0, 0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 48, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
             st.windows_valid = counters ? (int64_t)h_tot[2] : -1;
             st.slots_inspected = counters ? (int64_t)h_tot[3] : -1;
+            st.lookup_ran_off = h_tot[5] ? 1 : 0;
             if (windows) {
                 double ratio = (double)n_hits / (double)windows * 1.1 + 1e-3;
                 if (ratio > t->stage_ratio) t->stage_ratio = ratio > 1.0 ? 1.0 : ratio;
@@ -833,12 +834,13 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         HIP_TRY(hipEventRecord(t->ev[2], t->stream));
         st.scan_launches++;
         if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) { sc.adopt(d_stage); return rc; }
-        uint64_t h_tot[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 32, hipMemcpyDeviceToHost, t->stream));
+        uint64_t h_tot[6] = {0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 48, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         n_hits = n_rows ? h_tot[0] : 0;
         st.windows_valid = counters ? (int64_t)h_tot[2] : -1;
         st.slots_inspected = counters ? (int64_t)h_tot[3] : -1;
+        st.lookup_ran_off = h_tot[5] ? 1 : 0;
         if (h_tot[1] <= stage_cap) break;
         // staging overflow: now the exact need is known
         dfree(t, d_stage); d_stage = nullptr;

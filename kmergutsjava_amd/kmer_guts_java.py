@@ -16,8 +16,14 @@ Known, documented deviations from the reference's behaviour:
   * the progress lines "Processed: NN%, time=..." of the table stream (KGJ:1019-1025) are not
     printed: the table is not streamed;
   * -d: the HIT / after-hit / after-call stream is printed (from the library's event bytes), and so are
-    the info lines except "Kmers found: N (pos-count=M)" and the progress lines, which describe the
-    reference's table stream (KGJ:1019-1032);
+    the info lines incl. "Kmers found: N (pos-count=M)" (KGJ:1031-1033: N = distinct matched k-mer values,
+    M = hit records, over every FASTA record incl. records shadowed by a later one of the same id); only
+    the time-stamped progress lines of the reference's table stream are not (KGJ:1019-1025); when a query walks
+    off the end of the table the reference's stream throws EOFException and run() prints "Error: null" instead of
+    "Kmers found" (KGJ:797-802): so does this mirror (kg_stats.lookup_ran_off); a truncated table file makes a
+    .gz stream fail with "Error skipping N bytes" instead -- here it is "Error: null" as well;
+  * "Temp. directory:" prints the canonical path of /tmp, the JVM's java.io.tmpdir on Linux whatever
+    $TMPDIR says (KGJ:108, 744-748; -t can never change it, see below);
   * -t / -l: the reference's switch falls through to "Unknown parameter" for both (KGJ:605-611);
     this mirror does the same (message + usage, then carries on, KGJ:616-647);
   * input beyond 20 M k-mers: the reference silently drops queries in its external merge
@@ -154,6 +160,38 @@ def _read_text(path: str) -> str:
         return f.read().decode("latin-1")
 
 
+_AA_LUT = np.full(256, 20, dtype=np.int64)
+for _i, _c in enumerate("ACDEFGHIKLMNPQRSTVWY"):
+    _AA_LUT[ord(_c)] = _i
+_BASE_LUT = np.full(256, 4, dtype=np.int64)
+for _c, _v in (("a", 0), ("A", 0), ("c", 1), ("C", 1), ("g", 2), ("G", 2), ("t", 3), ("T", 3), ("u", 3), ("U", 3)):
+    _BASE_LUT[ord(_c)] = _v
+_CODON_AA = np.array([_AA_LUT[ord(c)] for c in "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF"], dtype=np.int64)
+_POW20 = 20 ** np.arange(7, -1, -1, dtype=np.int64)
+
+
+def hit_kmer_values(seq: bytes, aa: bool, positions_per_container) -> np.ndarray:
+    """encodedKmer (KGJ:274-292) of the window behind every hit record of one sequence: positions_per_container =
+    from0InProt arrays of its 1 (protein) or 6 (+0 +1 +2 -0 -1 -2, KGJ:1064-1072) containers.  Host side, for the
+    -d line "Kmers found" only (the hit records do not carry the k-mer)."""
+    s = np.frombuffer(seq, dtype=np.uint8)
+    out = []
+    if aa:
+        p = np.asarray(positions_per_container[0], dtype=np.int64)
+        out.append((_AA_LUT[s[p[:, None] + np.arange(8)[None, :]]] * _POW20).sum(axis=1))
+    else:
+        L = len(s)
+        b = _BASE_LUT[s]
+        for f in range(6):
+            p = np.asarray(positions_per_container[f], dtype=np.int64)
+            start = (f % 3) + 3 * p                                        # first base of the window on its strand
+            k = start[:, None] + np.arange(24)[None, :]
+            codes = b[k] if f < 3 else 3 - b[L - 1 - k]                    # revComp (KGJ:263-272): compl code = 3 - code
+            c = codes.reshape(-1, 8, 3)
+            out.append((_CODON_AA[c[:, :, 0] * 16 + c[:, :, 1] * 4 + c[:, :, 2]] * _POW20).sum(axis=1))
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
 _TABLES: Dict[Tuple[str, float, int, int], SignatureTable] = {}     # tables stay resident in HBM across run() calls
 
 
@@ -242,7 +280,7 @@ class KmerGutsJava:
 
     # ---- run (KGJ:742-820) ----
     def run(self, kmerTableDir: str, queryFastaFile: Optional[str], pw, stdout: bool) -> None:
-        self._info("Temp. directory: " + os.path.realpath(os.environ.get("TMPDIR", "/tmp")), pw, stdout)
+        self._info("Temp. directory: " + os.path.realpath("/tmp"), pw, stdout)     # KGJ:108: java.io.tmpdir
         table_path = os.path.join(kmerTableDir, "kmer.table.mem_map")
         if os.path.exists(table_path + ".gz"):
             table_path += ".gz"                                   # KGJ:750-753: the .gz wins
@@ -276,6 +314,7 @@ class KmerGutsJava:
         self.last_stats = []
         batch: List[int] = []
         size = 0
+        found_values: List[np.ndarray] = []     # -d: the k-mer value of every hit record (KGJ:1004-1015)
 
         def flush():
             nonlocal batch, size
@@ -293,14 +332,25 @@ class KmerGutsJava:
                 cs = range(j * per, j * per + per)
                 dbg = [(hits[chs[c]:chs[c + 1]], ev[chs[c]:chs[c + 1]], int(tail[c])) for c in cs] if self.debug else None
                 results[k] = ([calls[ccs[c]:ccs[c + 1]] for c in cs], otu[j], dbg)
+                if self.debug:
+                    found_values.append(hit_kmer_values(seqs[k], self.aa, [d[0]["from0InProt"] for d in dbg]))
             batch, size = [], 0
 
-        for k in order:
+        # -d counts what the reference's lookup counts: every FASTA record has containers of its own there, also a
+        # record that a later one of the same id shadows in the report (KGJ:805-809)
+        for k in (range(len(ids)) if self.debug else order):
             if batch and size + len(seqs[k]) > self.MAX_BATCH_CHARS:
                 flush()
             batch.append(k)
             size += len(seqs[k])
         flush()
+        if any(st["lookup_ran_off"] for st in self.last_stats):
+            # a query walked to the end of the table undecided: there the reference's stream throws EOFException,
+            # which run() reports and swallows (KGJ:797-802); the hits are the same, "Kmers found" is not reached
+            self._info("Error: null", pw, stdout)
+        elif self.debug:                                          # KGJ:1031-1033
+            vals = np.concatenate(found_values) if found_values else np.zeros(0, np.int64)
+            pw.write("Kmers found: %d (pos-count=%d)\n" % (len(np.unique(vals)), len(vals)))
         self._info("Lookup time: %d ms." % int((time.time() - t2) * 1000), pw, stdout)
 
         t3 = time.time()

@@ -356,14 +356,15 @@ static int lookup_literal(const uint8_t *file, int64_t file_n, int64_t numSigs, 
 /* Independent linear probing without wrap-around: the semantics the literal merge-join
  * implements.  Counts every table entry inspected. */
 static int lookup_direct(const uint8_t *file, int64_t file_n, int64_t numSigs,
-                         const query_kmer *qs, int64_t nq, hvec *hits, int64_t *inspected)
+                         const query_kmer *qs, int64_t nq, hvec *hits, int64_t *inspected, int32_t *ran_off)
 {
     /* the reference never compares the running slot with numSigs (KGJ:964-1026): a probe walk ends
      * at an empty slot, at the k-mer, or where the stream ends (EOF == not found) */
     int64_t limit = file_n / 24;
     for (int64_t k = 0; k < nq; k++) {
         int64_t v = qs[k].value;
-        for (int64_t s = v % numSigs; s < limit; s++) {
+        int64_t s;
+        for (s = v % numSigs; s < limit; s++) {
             const uint8_t *e = file + s * 24;
             int64_t whichKmer = rd_i64le(e);
             (*inspected)++;
@@ -378,6 +379,9 @@ static int lookup_direct(const uint8_t *file, int64_t file_n, int64_t numSigs,
                 break;
             }
         }
+        /* undecided at the end of the stream: where the reference's merge-join dies with EOFException (or cannot
+         * skip to the home slot of a truncated file), KGJ:799-802 */
+        if (s >= limit) *ran_off = 1;
     }
     return 0;
 }
@@ -621,7 +625,7 @@ int kgo_run(const uint8_t *table, size_t table_nbytes, const kgo_params *p,
             if (a) out->lookup_aborted = 1;
         } else {
             if (entrySize != 24) { rc = fail("direct-probe mode needs entrySize == 24"); break; }
-            if (lookup_direct(file, file_n, numSigs, q.a, q.n, &hits, &out->slots_inspected)) {
+            if (lookup_direct(file, file_n, numSigs, q.a, q.n, &hits, &out->slots_inspected, &out->lookup_aborted)) {
                 rc = fail("out of memory in lookup"); break;
             }
         }

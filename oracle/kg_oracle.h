@@ -64,7 +64,8 @@ typedef struct {
     int64_t slots_inspected;        /* table entries inspected, direct-probe count   */
     /* phase timers, KGJ:794,803,819 (seconds) */
     double t_prepare, t_lookup, t_group;
-    int32_t lookup_aborted;         /* literal mode: stream ran off the end (KGJ:799-802) in >=1 batch */
+    int32_t lookup_aborted;         /* the stream ran off the end (KGJ:799-802) in >=1 batch: literal mode = the merge-join
+                                       threw; direct mode = a probe walk reached the end of the records undecided */
     uint8_t *hit_events;            /* n_hits: KGO_EV_* of each record (the -d stream, see gather_sorted) */
     uint8_t *container_tail_events; /* n_containers: KGO_EV_TAIL_CALL                               */
 } kgo_result;

@@ -304,6 +304,8 @@ class Model:
 
     # ---- KGJ:944-1034 (literal merge-join over the table stream)
     def lookup(self, stream: io.BytesIO, num_sigs, entry_size, query_kmers, hit_cnts):
+        self.kmers_found = 0                                            # KGJ:956-957
+        self.pos_count = 0
         cur_hash = 0
         it = iter(query_kmers)
         cur = next(it, None)
@@ -336,9 +338,11 @@ class Model:
             if which > MAX_ENCODED:
                 in_progress.clear()
             elif which in in_progress:
+                self.kmers_found += 1                                   # KGJ:1005
                 for qk in in_progress.pop(which):
                     hit_cnts[qk[1]]["hits"].append(
                         Hit(otu_index, qk[2], avg_from_end, function_index, function_wt))
+                    self.pos_count += 1                                 # KGJ:1014
             cur_hash += 1
 
     # ---- KGJ:742-820
@@ -365,10 +369,13 @@ class Model:
                 return -1 if o1[0] < o2[0] else 1
             return 0
         query_kmers.sort(key=cmp_to_key(cmp))
+        self.info_lines = ["Kmer-table info: numSigs=%d, entrySize=%d, version=%d" % (num_sigs, entry_size, _version)]
         try:
             self.lookup(stream, num_sigs, entry_size, query_kmers, hit_cnts)
+            # KGJ:1031-1033 (debug only; not reached when the lookup ends in an exception)
+            self.info_lines.append("Kmers found: %d (pos-count=%d)" % (self.kmers_found, self.pos_count))
         except EOFError:
-            pass                                            # KGJ:799-802 swallowed
+            self.info_lines.append("Error: null")           # KGJ:799-802: EOFException() has no message; swallowed
         by_key = {}
         for cnt in hit_cnts:                                # KGJ:805-809 (later container wins)
             by_key[cnt["key"]] = cnt

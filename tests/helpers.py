@@ -20,6 +20,8 @@ def assert_same_records(gpu, ora, what=""):
     assert np.array_equal(ge, oe), "%s hit events differ at %s" % (what, np.flatnonzero(ge != oe)[:5])
     assert np.array_equal(gpu.container_tail_events(), ora["container_tail_events"]), what + " tail events"
     assert gpu.stats["residues"] == ora["residues"], what + " residues"
+    # where the reference's table stream would have thrown EOFException ("Error: null" instead of "Kmers found")
+    assert gpu.stats["lookup_ran_off"] == int(ora["lookup_aborted"]), what + " lookup_ran_off"
     import os
     mode = os.environ.get("KG_PARTITION")
     knobs = os.environ.get("KG_PART_OVF_GROUPS") is not None or os.environ.get("KG_PART_SLACK") is not None

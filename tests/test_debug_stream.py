@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-INFO = ("Temp. directory: ", "Preparation time: ", "Kmer-table info: ", "Lookup time: ", "Grouping time: ")
+INFO = ("Temp. directory: ", "Preparation time: ", "Kmer-table info: ", "Kmers found: ", "Error: ", "Lookup time: ", "Grouping time: ")
 
 CASES = [  # (dna, order_constraint, min_hits, max_gap, min_weighted_hits)
     (True, False, 3, 200, 0),
@@ -36,9 +36,13 @@ def _case(dna, seed):
     return img, sb, off, fa, fn
 
 
-def _model_text(img, fn, fa, dna, oc, mh, gap, mw):
+def _model_text(img, fn, fa, dna, oc, mh, gap, mw, info=None):
     from oracle import kgj_model as M
-    return M.Model(aa=not dna, order_constraint=oc, min_hits=mh, min_weighted_hits=mw, max_gap=gap, debug=True).run(img, fn, fa)
+    m = M.Model(aa=not dna, order_constraint=oc, min_hits=mh, min_weighted_hits=mw, max_gap=gap, debug=True)
+    text = m.run(img, fn, fa)
+    if info is not None:
+        info.extend(m.info_lines)       # "Kmer-table info: ...", "Kmers found: N (pos-count=M)" (KGJ:951-954, 1031-1033)
+    return text
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
@@ -94,7 +98,12 @@ def test_front_ends_print_the_debug_stream(case, tmp_path):
     from kmergutsjava_amd import synth, build, KmerGutsJava
     dna, oc, mh, gap, mw = CASES[case]
     img, sb, off, fa, fn = _case(dna, 700 + case)
-    want = _model_text(img, fn, fa, dna, oc, mh, gap, mw)
+    want_info = []
+    want = _model_text(img, fn, fa, dna, oc, mh, gap, mw, want_info)
+    if case == 1:       # a repeated id: reported once (last record wins, KGJ:805-809) but looked up twice (KGJ:1004-1015)
+        fa = fa + ">" + fa.split(">")[1]
+        want_info = []
+        want = _model_text(img, fn, fa, dna, oc, mh, gap, mw, want_info)
     synth.write_data_dir(str(tmp_path / "d"), img, 64, gz=False)
     (tmp_path / "q.fa").write_text(fa)
     args = ["-D", str(tmp_path / "d"), "-q", str(tmp_path / "q.fa"), "-d", "-m", str(mh), "-g", str(gap), "-M", str(mw)]
@@ -107,6 +116,33 @@ def test_front_ends_print_the_debug_stream(case, tmp_path):
     for name in ("py.txt", "cli.txt"):
         got, info = _strip_info((tmp_path / name).read_text())
         assert got == want, name
-        assert [ln.split(":")[0] for ln in info] == ["Temp. directory", "Preparation time", "Kmer-table info", "Lookup time",
-                                                     "Grouping time"], name
+        # the lookup ends with "Kmers found: N (pos-count=M)" or, when a query walks off the end of the table, with the
+        # swallowed EOFException's "Error: null" (KGJ:797-802, 1031-1033): whichever the literal model prints
+        assert [ln.split(":")[0] for ln in info] == ["Temp. directory", "Preparation time", "Kmer-table info",
+                                                     want_info[1].split(":")[0], "Lookup time", "Grouping time"], name
         assert "Kmer-table info: numSigs=1009, entrySize=24, version=1\n" in info, name
+        assert [ln.rstrip("\n") for ln in info[2:4]] == want_info, name          # incl. "Kmers found: N (pos-count=M)"
+        assert info[0] == "Temp. directory: " + os.path.realpath("/tmp") + "\n", name
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_kmers_found_line_from_hit_records(oracle, case):
+    """The -d line "Kmers found: N (pos-count=M)" (KGJ:1031-1033): the front ends recompute the k-mer behind every hit
+    record from the sequence characters; on the oracle's hit records that gives the literal model's counts."""
+    from kmergutsjava_amd.kmer_guts_java import hit_kmer_values
+    dna, oc, mh, gap, mw = CASES[case]
+    img, sb, off, fa, fn = _case(dna, 700 + case)
+    info = []
+    _model_text(img, fn, fa, dna, oc, mh, gap, mw, info)
+    o = oracle.run(img, sb, off, aa=not dna, order_constraint=oc, min_hits=mh, min_weighted_hits=mw, max_gap=gap)
+    per = 6 if dna else 1
+    chs = o["container_hit_start"]
+    vals = [hit_kmer_values(sb[off[s]:off[s + 1]], not dna,
+                            [o["hits"]["from0InProt"][chs[c]:chs[c + 1]] for c in range(s * per, s * per + per)])
+            for s in range(len(off) - 1)]
+    vals = np.concatenate(vals)
+    if o["lookup_aborted"]:              # a query walked off the end of this small table: the reference reports the EOF
+        assert info[1] == "Error: null"
+    else:
+        assert info[1] == "Kmers found: %d (pos-count=%d)" % (len(np.unique(vals)), len(vals))
+    assert len(np.unique(vals)) < len(vals)          # the fixture repeats k-mers: N != M

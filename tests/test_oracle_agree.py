@@ -39,8 +39,10 @@ def test_c_oracle_equals_python_model(oracle, dna, oc):
                         order_constraint=oc)
         for k in ("hits", "calls", "otu", "container_hit_start", "container_call_start"):
             assert o0[k].tobytes() == o1[k].tobytes(), k
+        assert o0["lookup_aborted"] == o1["lookup_aborted"]      # merge-join threw <=> a direct probe walked off the end
         m = M.Model(aa=not dna, order_constraint=oc, min_hits=mh, min_weighted_hits=mw, max_gap=gap)
         text = m.run(img, fn, _fasta(sb, off))
+        assert (m.info_lines[-1] == "Error: null") == o0["lookup_aborted"]   # KGJ:799-802 vs KGJ:1031-1033
         mh_ = np.array(m.hits, dtype=[("c", "<u4"), ("p", "<i4"), ("o", "<i4"), ("a", "<i4"), ("f", "<i4"), ("w", "<f4")])
         assert mh_.tobytes() == o0["hits"].tobytes()
         mc = np.array(m.calls, dtype=[("c", "<u4"), ("s", "<i4"), ("e", "<i4"), ("n", "<i4"), ("f", "<i4"), ("w", "<f4")]) \
