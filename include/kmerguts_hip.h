@@ -128,8 +128,9 @@ typedef struct kg_result kg_result;
 
 /* ---- signature table: replaces readKmerTableHeader (KGJ:924-942) + the table stream of lookup (KGJ:944-1034) ---- */
 
-/* Read <path> = an uncompressed kmer.table.mem_map (KGJ:749), validate the header
- * (3 x int64 LE: numSigs, entrySize, version) and make the table resident on HIP device <device>. */
+/* Read <path> = kmer.table.mem_map or kmer.table.mem_map.gz (KGJ:749-753; told apart by the gzip magic), validate the
+ * header (3 x int64 LE: numSigs, entrySize, version) and make the table resident on HIP device <device>.  The file is
+ * streamed through pinned buffers (several reader threads for a plain file, one zlib stream for .gz): no host copy. */
 int kg_table_open(const char *path, int device, kg_table **out);
 /* Same from a file image in host memory (the host gunzips kmer.table.mem_map.gz, KGJ:750-753). */
 int kg_table_from_memory(const void *image, size_t nbytes, int device, kg_table **out);
@@ -160,6 +161,9 @@ const int64_t *kg_result_container_call_start(kg_result *r); /* n_containers + 1
 const kg_otu  *kg_result_otu(kg_result *r);                  /* n_seqs                                        */
 const uint8_t *kg_result_hit_events(kg_result *r);           /* n_hits bytes of KG_EV_*                        */
 const uint8_t *kg_result_container_tail_events(kg_result *r);/* n_containers bytes of KG_EV_TAIL_*             */
+/* hits[first .. first + count) straight into caller-owned memory (e.g. a JNA Memory / numpy array); pageable
+ * destinations are fed through the library's cached pinned blocks, the copy overlapped with the transfer. */
+int kg_result_copy_hits(kg_result *r, int64_t first, int64_t count, kg_hit *dst);
 /* Device views (valid until kg_result_free) for callers that keep working in HBM. */
 const void    *kg_result_device_hits(const kg_result *r);
 const void    *kg_result_device_calls(const kg_result *r);

@@ -69,6 +69,7 @@ public interface KmerGutsHip extends Library {
     Pointer kg_result_container_tail_events(Pointer result); // byte[n_containers]  KG_EV_TAIL_CALL
     Pointer kg_result_device_hits(Pointer result);
     Pointer kg_result_device_calls(Pointer result);
+    int kg_result_copy_hits(Pointer result, long first, long count, Pointer dst);
     Pointer kg_result_device_otu(Pointer result);
     Pointer kg_result_device_container_hit_start(Pointer result);
     Pointer kg_result_device_container_call_start(Pointer result);

@@ -23,7 +23,7 @@ EXPORTS = (
     "kg_table_open", "kg_table_from_memory", "kg_table_from_device", "kg_table_info", "kg_table_close",
     "kg_scan", "kg_scan_device", "kg_result_stats", "kg_result_hits", "kg_result_container_hit_start",
     "kg_result_calls", "kg_result_container_call_start", "kg_result_otu", "kg_result_hit_events",
-    "kg_result_container_tail_events", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu",
+    "kg_result_container_tail_events", "kg_result_copy_hits", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu",
     "kg_result_device_container_hit_start", "kg_result_device_container_call_start", "kg_result_free", "kg_last_error", "kg_version",
 )
 
@@ -94,6 +94,7 @@ def load() -> C.CDLL:
                  "kg_result_device_container_hit_start", "kg_result_device_container_call_start"):
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = vp
+    lib.kg_result_copy_hits.argtypes = [vp, C.c_int64, C.c_int64, vp]
     lib.kg_result_free.argtypes = [vp]
     lib.kg_result_free.restype = None
     lib.kg_last_error.restype = C.c_char_p

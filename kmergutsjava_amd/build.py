@@ -36,7 +36,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, "kmerguts_hip.hip")] + sorted(
         os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(ROOT, "include", "kmerguts_hip.h")]
     if force or _stale(LIB, srcs):
-        cmd = [_hipcc(), *HIPCC_FLAGS, "-o", LIB, srcs[0]]
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-o", LIB, srcs[0], "-lz", "-lpthread"]      # zlib: kmer.table.mem_map.gz
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
@@ -52,7 +52,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
     src = os.path.join(CSRC, "kmer_guts_cli.cpp")
     if force or _stale(CLI, [src, os.path.join(ROOT, "include", "kmerguts_hip.h")]):
         cxx = shutil.which("g++") or shutil.which("hipcc")
-        cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-o", CLI, src, "-L" + HERE, "-lkmerguts_hip", "-lz",
+        cmd = [cxx, "-O2", "-std=c++17", "-Wall", "-pthread", "-o", CLI, src, "-L" + HERE, "-lkmerguts_hip", "-lz",
                "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

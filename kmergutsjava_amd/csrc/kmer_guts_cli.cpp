@@ -12,6 +12,10 @@
 // is printed and execution continues (KGJ:616-647); a missing -q is an error (new File(null), KGJ:647).
 // Differences: no "Processed: NN%" lines (the table is not streamed); -d prints the info lines only.
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <cerrno>
 #include <cmath>
@@ -21,6 +25,7 @@
 #include <cstring>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -72,8 +77,11 @@ struct Lines {
     {
         if (p >= end) return false;
         b = p;
-        while (p < end && *p != '\n' && *p != '\r') p++;
-        e = p;
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *stop = nl ? nl : end;
+        const char *cr = (const char *)memchr(p, '\r', (size_t)(stop - p));      // a lone \r ends a line too
+        if (cr) stop = cr;
+        p = e = stop;
         if (p < end) {
             if (*p == '\r' && p + 1 < end && p[1] == '\n') p++;
             p++;
@@ -118,12 +126,13 @@ struct Fasta {
     std::vector<int64_t> off{0};
 };
 
-void read_fasta(const std::vector<char> &text, Fasta &fa)
+// the reference's reader over text[0, n); throws Fatal exactly where (and with the message) the reference throws
+void read_fasta_range(const char *text, size_t n, Fasta &fa)
 {
-    Lines ln{text.data(), text.data() + text.size()};
+    Lines ln{text, text + n};
     const char *b = nullptr, *e = nullptr;
     bool have = false;                  // str1 carried over from the previous record
-    fa.seq.reserve(text.size());
+    fa.seq.reserve(n);
     for (;;) {
         std::string name;
         bool got_name = false;
@@ -169,6 +178,94 @@ void read_fasta(const std::vector<char> &text, Fasta &fa)
         fa.ids.push_back(std::move(name));
         fa.off.push_back((int64_t)fa.seq.size());
     }
+}
+
+// A line whose trimmed form starts with '>' ends the record before it whatever follows (KGJ:1163-1180), so the text
+// can be cut in front of such lines and the pieces read independently: the records, their order and the first
+// error in file order are those of one sequential pass.
+void read_fasta(const char *text, size_t n, Fasta &fa)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    size_t n_thr = std::min<size_t>(16, hw ? hw : 4);
+    const char *tv = getenv("KG_FASTA_THREADS");                 // tests force several pieces on small inputs
+    if (tv && atoi(tv) > 0) n_thr = (size_t)atoi(tv);
+    else if (n < (8u << 20)) n_thr = 1;
+    std::vector<size_t> cut{0};
+    for (size_t k = 1; k < n_thr; k++) {
+        size_t p = n / n_thr * k;
+        if (p <= cut.back()) continue;
+        // the first line start at or after p whose first character > ' ' is '>'
+        const char *q = (const char *)memchr(text + p - 1, '\n', n - p + 1);      // (a \r-only file is read by one thread)
+        while (q) {
+            const char *ls = q + 1, *c = ls;
+            while (c < text + n && (unsigned char)*c <= ' ' && *c != '\n' && *c != '\r') c++;
+            if (c < text + n && *c == '>') { cut.push_back((size_t)(ls - text)); break; }
+            q = (const char *)memchr(ls, '\n', (size_t)(text + n - ls));
+        }
+        if (!q) break;
+    }
+    cut.push_back(n);
+    const size_t parts = cut.size() - 1;
+    if (parts == 1) { read_fasta_range(text, n, fa); return; }
+    std::vector<Fasta> part(parts);
+    std::vector<std::string> err(parts);
+    std::vector<char> failed(parts, 0);
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < parts; k++)
+            pool.emplace_back([&, k]() {
+                try { read_fasta_range(text + cut[k], cut[k + 1] - cut[k], part[k]); }
+                catch (const Fatal &f) { failed[k] = 1; err[k] = f.msg; }
+            });
+        for (auto &t : pool) t.join();
+    }
+    // a piece that stops at an error still holds the records in front of it; the sequential reader would have thrown
+    // there too, after the same records -- nothing is reported in that case, so only the message matters
+    for (size_t k = 0; k < parts; k++)
+        if (failed[k]) die(err[k]);
+    size_t total = 0, n_ids = 0;
+    std::vector<size_t> base(parts);
+    for (size_t k = 0; k < parts; k++) { base[k] = total; total += part[k].seq.size(); n_ids += part[k].ids.size(); }
+    fa.seq.resize(total);
+    fa.ids.reserve(n_ids);
+    fa.off.reserve(n_ids + 1);
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < parts; k++)
+            pool.emplace_back([&, k]() { if (!part[k].seq.empty()) memcpy(fa.seq.data() + base[k], part[k].seq.data(), part[k].seq.size()); });
+        for (auto &t : pool) t.join();
+    }
+    for (size_t k = 0; k < parts; k++) {
+        for (auto &id : part[k].ids) fa.ids.push_back(std::move(id));
+        for (size_t r = 1; r < part[k].off.size(); r++) fa.off.push_back((int64_t)base[k] + part[k].off[r]);
+    }
+}
+
+// the query text: a plain file is mapped, not copied; .gz and stdin are read into memory
+struct Text {
+    const char *p = nullptr;
+    size_t n = 0;
+    std::vector<char> owned;
+    void *map = nullptr;
+    ~Text() { if (map) munmap(map, n); }
+};
+
+void load_text(const std::string &path, Text &t)
+{
+    const bool gz = path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    if (!gz && path != "-") {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) die(path + " (No such file or directory)");
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            close(fd);
+            if (m != MAP_FAILED) { t.map = m; t.p = (const char *)m; t.n = (size_t)st.st_size; return; }
+        } else close(fd);
+    }
+    t.owned = read_all(path);
+    t.p = t.owned.data();
+    t.n = t.owned.size();
 }
 
 // ---- String.format("%f") of a float: decimal digits of (double)v rounded HALF_UP (java.util.Formatter) ----
@@ -304,6 +401,7 @@ static int64_t kmer_value_at(const uint8_t *s, int64_t len, bool aa, int f, int3
     return v;
 }
 
+#ifndef KG_CLI_NO_MAIN
 int main(int argc, char **argv)
 {
     Options o;
@@ -330,16 +428,15 @@ int main(int argc, char **argv)
         const std::vector<std::string> functions = load_indexed_array(read_all(fidx));
 
         kg_table *tab = nullptr;
-        if (table.size() > 3 && table.compare(table.size() - 3, 3, ".gz") == 0) {
-            std::vector<char> img = read_all(table);
-            check(kg_table_from_memory(img.data(), img.size(), 0, &tab));
-        } else {
-            check(kg_table_open(table.c_str(), 0, &tab));
-        }
+        check(kg_table_open(table.c_str(), 0, &tab));             // plain or .gz: streamed to the device by the library
 
         long long t1 = now_ms();
         Fasta fa;
-        read_fasta(read_all(o.query), fa);
+        {
+            Text text;
+            load_text(o.query, text);
+            read_fasta(text.p, text.n, fa);
+        }
         info("Preparation time: " + std::to_string(now_ms() - t1) + " ms.");
 
         // queryIdToLen / hitCnts are maps (KGJ:772, 805-809): a repeated id is reported once, at the place of its
@@ -530,3 +627,4 @@ int main(int argc, char **argv)
     }
     return 0;
 }
+#endif  // KG_CLI_NO_MAIN

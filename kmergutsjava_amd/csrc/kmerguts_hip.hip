@@ -9,7 +9,12 @@
 #include "kg_aggregate.hpp"
 #include "kg_partition.hpp"
 
+#include <fcntl.h>
+#include <unistd.h>
+#include <zlib.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -19,6 +24,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -94,13 +100,15 @@ struct DevCache {
     }
 };
 
-// Pinned host blocks for the result views (hipHostMalloc / hipHostFree cost ~0.1-0.2 ms each: more than a small
-// scan).  Only blocks up to 64 MiB are kept.
+// Pinned host blocks for the result views.  hipHostMalloc / hipHostFree cost ~0.1-0.2 ms for a small block (more than
+// a small scan) and ~0.5 s for the 880 MB of hit records of a 1 Gbp batch (page pinning: the copy itself takes 20 ms at
+// PCIe rate), so blocks are kept for the next result: up to kKeepTotal bytes, largest dropped first.
 struct PinCache {
     std::mutex mu;
     std::multimap<size_t, void *> free_;
     std::unordered_map<void *, size_t> live;
-    static constexpr size_t kKeepMax = 64u << 20;
+    size_t kept = 0;
+    static constexpr size_t kKeepTotal = 6ull << 30;
 
     hipError_t get(void **p, size_t bytes)
     {
@@ -111,6 +119,7 @@ struct PinCache {
             if (it != free_.end() && it->first <= 2 * bytes + (1u << 16)) {
                 *p = it->second;
                 live[*p] = it->first;
+                kept -= it->first;
                 free_.erase(it);
                 return hipSuccess;
             }
@@ -123,16 +132,23 @@ struct PinCache {
     }
     void put(void *p)
     {
-        size_t bytes = 0;
+        std::vector<void *> drop;
         {
             std::lock_guard<std::mutex> lk(mu);
             auto it = live.find(p);
             if (it == live.end()) return;
-            bytes = it->second;
+            const size_t bytes = it->second;
             live.erase(it);
-            if (bytes <= kKeepMax) { free_.emplace(bytes, p); return; }
+            free_.emplace(bytes, p);
+            kept += bytes;
+            while (kept > kKeepTotal && !free_.empty()) {          // largest first
+                auto big = std::prev(free_.end());
+                kept -= big->first;
+                drop.push_back(big->second);
+                free_.erase(big);
+            }
         }
-        (void)hipHostFree(p);
+        for (void *d : drop) (void)hipHostFree(d);
     }
     void release_all()
     {
@@ -141,6 +157,7 @@ struct PinCache {
         for (auto &kv : live) (void)hipHostFree(kv.first);
         free_.clear();
         live.clear();
+        kept = 0;
     }
 };
 
@@ -305,27 +322,28 @@ int kg_table_from_memory(const void *image, size_t nbytes, int device, kg_table 
     return KG_OK;
 }
 
-int kg_table_open(const char *path, int device, kg_table **out)
+// gzip members are inflated by one zlib stream (a gzip stream has no block index: it cannot be cut for several
+// threads); what can overlap does: the inflate of piece k+1 with the upload of piece k, and no host copy of the
+// table is ever held (the reference's GZIPInputStream is a stream too, KGJ:749-753, 927-929).
+static int open_gz(const char *path, int device, kg_table **out)
 {
-    if (!path || !out) return fail(KG_ERR_ARG, "null argument");
-    FILE *f = fopen(path, "rb");
-    if (!f) return fail(KG_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
+    gzFile g = gzopen(path, "rb");
+    if (!g) return fail(KG_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
+    gzbuffer(g, 1u << 20);
     uint8_t hdr[24];
-    if (fread(hdr, 1, 24, f) != 24) { fclose(f); return fail(KG_ERR_FORMAT, "kmer table file shorter than its 24-byte header"); }
-    if (fseeko(f, 0, SEEK_END) != 0) { fclose(f); return fail(KG_ERR_IO, "fseek failed"); }
-    off_t fsz = ftello(f);
-    if (fseeko(f, 24, SEEK_SET) != 0) { fclose(f); return fail(KG_ERR_IO, "fseek failed"); }
+    if (gzread(g, hdr, 24) != 24) { gzclose(g); return fail(KG_ERR_FORMAT, "kmer table file shorter than its 24-byte header"); }
     kg_table *t = nullptr;
     int rc = table_new(device, &t);
-    if (rc) { fclose(f); return rc; }
+    if (rc) { gzclose(g); return rc; }
     rc = parse_header(hdr, t);
-    if (rc) { fclose(f); kg_table_close(t); return rc; }
-    t->limit = (uint64_t)(fsz - 24) / KG_TABLE_ENTRY_SIZE;
-    size_t bytes = (size_t)t->limit * KG_TABLE_ENTRY_SIZE;
+    if (rc) { gzclose(g); kg_table_close(t); return rc; }
+    // the header says how many records to expect; a stream that holds more keeps being read by the reference, so the
+    // device buffer grows when it has to
+    size_t cap = (size_t)t->num_sigs * KG_TABLE_ENTRY_SIZE;
+    if (cap < 256) cap = 256;
     t->own_entries = true;
-    hipError_t e = hipMalloc((void **)&t->d_entries, bytes ? bytes : 256);
-    if (e != hipSuccess) { fclose(f); kg_table_close(t); return fail(KG_ERR_NOMEM, std::string("hipMalloc(table): ") + hipGetErrorString(e)); }
-    // stream the file through two pinned 64 MiB buffers
+    hipError_t e = hipMalloc((void **)&t->d_entries, cap);
+    if (e != hipSuccess) { gzclose(g); kg_table_close(t); return fail(KG_ERR_NOMEM, std::string("hipMalloc(table): ") + hipGetErrorString(e)); }
     const size_t CH = 64u << 20;
     uint8_t *pin[2] = {nullptr, nullptr};
     hipEvent_t done[2];
@@ -334,11 +352,27 @@ int kg_table_open(const char *path, int device, kg_table **out)
     size_t at = 0;
     int which = 0;
     bool used[2] = {false, false};
-    while (ok && at < bytes) {
-        size_t n = bytes - at < CH ? bytes - at : CH;
+    std::string why;
+    while (ok) {
         if (used[which]) ok = hipEventSynchronize(done[which]) == hipSuccess;
         if (!ok) break;
-        if (fread(pin[which], 1, n, f) != n) { ok = false; g_err = "short read on kmer table file"; break; }
+        size_t n = 0;
+        while (n < CH) {                                   // gzread takes an unsigned int
+            const int got = gzread(g, pin[which] + n, (unsigned)std::min<size_t>(CH - n, 1u << 30));
+            if (got < 0) { int en = 0; why = gzerror(g, &en); ok = false; break; }
+            if (got == 0) break;
+            n += (size_t)got;
+        }
+        if (!ok || n == 0) break;
+        if (at + n > cap) {
+            size_t ncap = std::max(at + n, cap + cap / 2);
+            uint8_t *bigger = nullptr;
+            ok = hipStreamSynchronize(t->stream) == hipSuccess && hipMalloc((void **)&bigger, ncap) == hipSuccess &&
+                 hipMemcpy(bigger, t->d_entries, at, hipMemcpyDeviceToDevice) == hipSuccess;
+            if (!ok) { if (bigger) (void)hipFree(bigger); why = "out of device memory for a table longer than its header says"; break; }
+            (void)hipFree(t->d_entries);
+            t->d_entries = bigger; cap = ncap;
+        }
         ok = hipMemcpyAsync(t->d_entries + at, pin[which], n, hipMemcpyHostToDevice, t->stream) == hipSuccess &&
              hipEventRecord(done[which], t->stream) == hipSuccess;
         used[which] = true;
@@ -346,12 +380,97 @@ int kg_table_open(const char *path, int device, kg_table **out)
         which ^= 1;
     }
     if (ok) ok = hipStreamSynchronize(t->stream) == hipSuccess;
-    fclose(f);
+    gzclose(g);
     if (pin[0]) (void)hipHostFree(pin[0]);
     if (pin[1]) (void)hipHostFree(pin[1]);
     (void)hipEventDestroy(done[0]);
     (void)hipEventDestroy(done[1]);
-    if (!ok) { kg_table_close(t); return fail(KG_ERR_IO, "reading/uploading the kmer table failed" + (g_err.empty() ? std::string() : ": " + g_err)); }
+    if (!ok) { kg_table_close(t); return fail(KG_ERR_IO, "inflating/uploading the kmer table failed" + (why.empty() ? std::string() : ": " + why)); }
+    t->limit = at / KG_TABLE_ENTRY_SIZE;                  // a trailing partial record is an EOF for the reference
+    rc = table_finish(t);
+    if (rc) { kg_table_close(t); return rc; }
+    *out = t;
+    return KG_OK;
+}
+
+int kg_table_open(const char *path, int device, kg_table **out)
+{
+    if (!path || !out) return fail(KG_ERR_ARG, "null argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(KG_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
+    uint8_t hdr[24];
+    const size_t got_hdr = fread(hdr, 1, 24, f);
+    if (got_hdr >= 2 && hdr[0] == 0x1f && hdr[1] == 0x8b) {          // gzip magic: kmer.table.mem_map.gz
+        fclose(f);
+        return open_gz(path, device, out);
+    }
+    if (got_hdr != 24) { fclose(f); return fail(KG_ERR_FORMAT, "kmer table file shorter than its 24-byte header"); }
+    if (fseeko(f, 0, SEEK_END) != 0) { fclose(f); return fail(KG_ERR_IO, "fseek failed"); }
+    off_t fsz = ftello(f);
+    fclose(f);
+    kg_table *t = nullptr;
+    int rc = table_new(device, &t);
+    if (rc) return rc;
+    rc = parse_header(hdr, t);
+    if (rc) { kg_table_close(t); return rc; }
+    t->limit = (uint64_t)(fsz - 24) / KG_TABLE_ENTRY_SIZE;
+    size_t bytes = (size_t)t->limit * KG_TABLE_ENTRY_SIZE;
+    t->own_entries = true;
+    hipError_t e = hipMalloc((void **)&t->d_entries, bytes ? bytes : 256);
+    if (e != hipSuccess) { kg_table_close(t); return fail(KG_ERR_NOMEM, std::string("hipMalloc(table): ") + hipGetErrorString(e)); }
+    // Several reader threads pread() disjoint 32 MiB pieces of the file into their own pinned buffers (two each) and
+    // hand them to the copy engine: one thread's read() runs at the page cache's single-core memcpy rate (~5 GB/s),
+    // a 33.6 GB table should load at what the PCIe link takes.
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { kg_table_close(t); return fail(KG_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno)); }
+    const size_t CH = 32u << 20;
+    const size_t n_pieces = (bytes + CH - 1) / CH;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_thr = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(hw ? hw : 4), n_pieces}));
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    std::mutex err_mu;
+    std::string why;
+    auto worker = [&]() {
+        if (hipSetDevice(device) != hipSuccess) { ok = false; return; }
+        hipStream_t s = nullptr;
+        uint8_t *pin[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        bool good = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
+                    hipHostMalloc((void **)&pin[0], CH) == hipSuccess && hipHostMalloc((void **)&pin[1], CH) == hipSuccess &&
+                    hipEventCreate(&done[0]) == hipSuccess && hipEventCreate(&done[1]) == hipSuccess;
+        bool used[2] = {false, false};
+        int which = 0;
+        while (good && ok.load()) {
+            const size_t k = next.fetch_add(1);
+            if (k >= n_pieces) break;
+            const size_t at = k * CH, n = std::min(CH, bytes - at);
+            if (used[which]) good = hipEventSynchronize(done[which]) == hipSuccess;
+            size_t got = 0;
+            while (good && got < n) {
+                const ssize_t r = pread(fd, pin[which] + got, n - got, (off_t)(24 + at + got));
+                if (r <= 0) { std::lock_guard<std::mutex> lk(err_mu); why = "short read on kmer table file"; good = false; break; }
+                got += (size_t)r;
+            }
+            if (!good) break;
+            good = hipMemcpyAsync(t->d_entries + at, pin[which], n, hipMemcpyHostToDevice, s) == hipSuccess &&
+                   hipEventRecord(done[which], s) == hipSuccess;
+            used[which] = true;
+            which ^= 1;
+        }
+        if (s) (void)hipStreamSynchronize(s);
+        if (!good) ok = false;
+        for (int i = 0; i < 2; i++) { if (pin[i]) (void)hipHostFree(pin[i]); if (done[i]) (void)hipEventDestroy(done[i]); }
+        if (s) (void)hipStreamDestroy(s);
+    };
+    {
+        std::vector<std::thread> pool;
+        for (size_t i = 1; i < n_thr; i++) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+    }
+    close(fd);
+    if (!ok.load()) { kg_table_close(t); return fail(KG_ERR_IO, "reading/uploading the kmer table failed" + (why.empty() ? std::string() : ": " + why)); }
     rc = table_finish(t);
     if (rc) { kg_table_close(t); return rc; }
     *out = t;
@@ -1040,6 +1159,55 @@ const uint8_t *kg_result_container_tail_events(kg_result *r)
     if (!r->d_tail_ev) { g_err = "events not computed (KG_F_SKIP_AGGREGATE)"; return nullptr; }
     return host_view(r, r->h_tail_ev, r->d_tail_ev, (size_t)r->st.n_containers);
 }
+int kg_result_copy_hits(kg_result *r, int64_t first, int64_t count, kg_hit *dst)
+{
+    if (!r || first < 0 || count < 0 || first + count > r->st.n_hits) return fail(KG_ERR_ARG, "hit range out of bounds");
+    if (count == 0) return KG_OK;
+    if (!dst) return fail(KG_ERR_ARG, "null destination");
+    HIP_TRY(hipSetDevice(r->tab->device));
+    // pageable destinations go through the table's two cached pinned blocks, 64 MiB at a time: the device-to-host copy
+    // of piece k+1 runs while piece k is moved into the caller's memory
+    hipPointerAttribute_t attr;
+    const bool pinned_dst = hipPointerGetAttributes(&attr, dst) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    if (pinned_dst) {
+        HIP_TRY(hipMemcpy(dst, r->d_hits + first, (size_t)count * sizeof(kg_hit), hipMemcpyDeviceToHost));
+        return KG_OK;
+    }
+    const size_t piece = (64u << 20) / sizeof(kg_hit);
+    void *stage[2] = {nullptr, nullptr};
+    for (auto &st : stage)
+        if (r->tab->pins.get(&st, piece * sizeof(kg_hit)) != hipSuccess) {
+            if (stage[0]) r->tab->pins.put(stage[0]);
+            return fail(KG_ERR_NOMEM, "pinned staging allocation failed");
+        }
+    hipStream_t s = r->tab->stream;
+    hipEvent_t done[2] = {r->tab->ev[6], r->tab->ev[0]};      // idle outside a scan
+    int rc = KG_OK;
+    int64_t sent = 0, got = 0;
+    int which = 0;
+    auto issue = [&](int w) {
+        const int64_t n = std::min<int64_t>((int64_t)piece, count - sent);
+        hipError_t e = hipMemcpyAsync(stage[w], r->d_hits + first + sent, (size_t)n * sizeof(kg_hit), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipEventRecord(done[w], s);
+        if (e != hipSuccess) rc = fail(KG_ERR_DEVICE, std::string("device to host copy failed: ") + hipGetErrorString(e));
+        sent += n;
+    };
+    issue(0);
+    while (rc == KG_OK && got < count) {
+        if (sent < count) issue(which ^ 1);
+        if (rc != KG_OK) break;
+        if (hipEventSynchronize(done[which]) != hipSuccess) { rc = fail(KG_ERR_DEVICE, "device to host copy failed"); break; }
+        const int64_t n = std::min<int64_t>((int64_t)piece, count - got);
+        memcpy(dst + got, stage[which], (size_t)n * sizeof(kg_hit));
+        got += n;
+        which ^= 1;
+    }
+    (void)hipStreamSynchronize(s);
+    r->tab->pins.put(stage[0]); r->tab->pins.put(stage[1]);
+    return rc;
+}
+
 const void *kg_result_device_hits(const kg_result *r) { return r ? r->d_hits : nullptr; }
 const void *kg_result_device_calls(const kg_result *r) { return r ? r->d_calls : nullptr; }
 const void *kg_result_device_otu(const kg_result *r) { return r ? r->d_otu : nullptr; }

@@ -73,6 +73,16 @@ class ScanResult:
         lib = self._need()
         return N.view(lib.kg_result_hits(self._h), self.stats["n_hits"], N.HIT_DTYPE, None if copy else self)
 
+    def copy_hits(self, first: int = 0, count: Optional[int] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """hits[first : first + count] into caller-owned memory (a new array unless `out` is given)."""
+        lib = self._need()
+        count = self.stats["n_hits"] - first if count is None else count
+        if out is None:
+            out = np.empty(count, dtype=N.HIT_DTYPE)
+        assert out.dtype == N.HIT_DTYPE and out.flags.c_contiguous and len(out) >= count
+        N.check(lib.kg_result_copy_hits(self._h, first, count, out.ctypes.data if count else None))
+        return out[:count]
+
     def container_hit_start(self) -> np.ndarray:
         lib = self._need()
         return N.view(lib.kg_result_container_hit_start(self._h), self.stats["n_containers"] + 1, np.dtype("<i8"))

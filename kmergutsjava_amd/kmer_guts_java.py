@@ -200,11 +200,7 @@ def _resident_table(path: str, device: int) -> SignatureTable:
     key = (os.path.realpath(path), st.st_mtime, st.st_size, device)
     tab = _TABLES.get(key)
     if tab is None:
-        if path.endswith(".gz"):
-            with gzip.open(path, "rb") as f:
-                tab = SignatureTable.from_bytes(f.read(), device)
-        else:
-            tab = SignatureTable.open(path, device)
+        tab = SignatureTable.open(path, device)        # plain or .gz (KGJ:749-753): the library streams it to the device
         _TABLES[key] = tab
     return tab
 
