@@ -152,6 +152,19 @@ int kg_scan(kg_table *t, const kg_params *p, const uint8_t *seq, const int64_t *
 int kg_scan_device(kg_table *t, const kg_params *p, const uint8_t *d_seq, const int64_t *offsets,
                    int64_t n_seqs, kg_result **out);
 
+/* ---- the aggregation alone: replaces the public gatherHits / processSetOfHits / processAASeq (KGJ:385-514, 526-536) for
+ *      callers that hold hit records of their own.  hits[] ordered by (container, from0InProt), container_hit_start[n_seqs *
+ *      (aa ? 1 : 6) + 1]; otu_init = the oICounts buffer every sequence starts with (n_seqs records) or NULL for empty
+ *      buffers (KGJ:528, 540).  The result has the hit, CALL, OTU and event arrays (no table, no scan statistics). ---- */
+int kg_aggregate_hits(int device, const kg_params *p, const kg_hit *hits, const int64_t *container_hit_start, int64_t n_seqs,
+                      const kg_otu *otu_init, kg_result **out);
+
+/* One step of that state machine, the public processSetOfHits (KGJ:385-455): votes for current_fi among hits[0..n_hits),
+ * *called / *call = whether a CALL was made and its record, *otu = the caller's oICounts buffer (updated in place),
+ * *new_current_fi = the method's return value, *keeps_last_two = the list keeps hits[n-2], hits[n-1] (else it is emptied). */
+int kg_process_set_of_hits(int device, const kg_params *p, const kg_hit *hits, int32_t n_hits, int32_t current_fi, kg_otu *otu,
+                           kg_call *call, int32_t *called, int32_t *new_current_fi, int32_t *keeps_last_two);
+
 int kg_result_stats(const kg_result *r, kg_stats *out);
 /* Host views, copied from the device on first use; NULL on failure (see kg_last_error). */
 const kg_hit  *kg_result_hits(kg_result *r);                 /* n_hits, ordered by (container, from0InProt)   */

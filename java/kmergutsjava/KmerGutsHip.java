@@ -4,6 +4,7 @@ import com.sun.jna.Library;
 import com.sun.jna.Native;
 import com.sun.jna.Pointer;
 import com.sun.jna.Structure;
+import com.sun.jna.ptr.IntByReference;
 import com.sun.jna.ptr.PointerByReference;
 
 import java.util.Arrays;
@@ -59,6 +60,10 @@ public interface KmerGutsHip extends Library {
     int kg_scan(Pointer table, KgParams params, byte[] seq, long[] offsets, long nSeqs, PointerByReference out);
     int kg_scan_device(Pointer table, KgParams params, Pointer dSeq, long[] offsets, long nSeqs, PointerByReference out);
 
+    int kg_aggregate_hits(int device, KgParams params, Pointer hits, Pointer containerHitStart, long nSeqs, Pointer otuInit,
+                          PointerByReference out);
+    int kg_process_set_of_hits(int device, KgParams params, Pointer hits, int nHits, int currentFI, Pointer otu, Pointer call,
+                               IntByReference called, IntByReference newCurrentFI, IntByReference keepsLastTwo);
     int kg_result_stats(Pointer result, KgStats out);
     Pointer kg_result_hits(Pointer result);                  // kg_hit[n_hits]   24 B each
     Pointer kg_result_container_hit_start(Pointer result);   // int64[n_containers + 1]

@@ -21,7 +21,7 @@ KG_OI_BUFSZ = 5
 # every symbol include/kmerguts_hip.h declares
 EXPORTS = (
     "kg_table_open", "kg_table_from_memory", "kg_table_from_device", "kg_table_info", "kg_table_close",
-    "kg_scan", "kg_scan_device", "kg_result_stats", "kg_result_hits", "kg_result_container_hit_start",
+    "kg_scan", "kg_scan_device", "kg_aggregate_hits", "kg_process_set_of_hits", "kg_result_stats", "kg_result_hits", "kg_result_container_hit_start",
     "kg_result_calls", "kg_result_container_call_start", "kg_result_otu", "kg_result_hit_events",
     "kg_result_container_tail_events", "kg_result_copy_hits", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu",
     "kg_result_device_container_hit_start", "kg_result_device_container_call_start", "kg_result_free", "kg_last_error", "kg_version",
@@ -87,6 +87,9 @@ def load() -> C.CDLL:
     lib.kg_table_close.restype = None
     lib.kg_scan.argtypes = [vp, C.POINTER(KgParams), vp, vp, C.c_int64, C.POINTER(vp)]
     lib.kg_scan_device.argtypes = [vp, C.POINTER(KgParams), vp, vp, C.c_int64, C.POINTER(vp)]
+    lib.kg_aggregate_hits.argtypes = [C.c_int, C.POINTER(KgParams), vp, vp, C.c_int64, vp, C.POINTER(vp)]
+    i32p = C.POINTER(C.c_int32)
+    lib.kg_process_set_of_hits.argtypes = [C.c_int, C.POINTER(KgParams), vp, C.c_int32, C.c_int32, vp, vp, i32p, i32p, i32p]
     lib.kg_result_stats.argtypes = [vp, C.POINTER(KgStats)]
     for name in ("kg_result_hits", "kg_result_container_hit_start", "kg_result_calls",
                  "kg_result_container_call_start", "kg_result_otu", "kg_result_hit_events",

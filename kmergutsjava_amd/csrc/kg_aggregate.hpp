@@ -318,13 +318,19 @@ __global__ void call_starts_kernel(const uint32_t *call_off, uint64_t n_cont, co
 __global__ __launch_bounds__(256) void otu_wave_kernel(const kg_hit *__restrict__ hits, const uint8_t *__restrict__ acc,
                                                        const kg_call *__restrict__ calls, const CallSpan *__restrict__ spans,
                                                        const int64_t *__restrict__ ccs, uint32_t n_seqs, uint32_t per,
-                                                       kg_otu *otu, uint32_t per_wave)
+                                                       kg_otu *otu, uint32_t per_wave, const kg_otu *__restrict__ otu_init)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t s_first = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6))) * per_wave;
     for (uint32_t s = s_first; s < s_first + per_wave && s < n_seqs; s++) {
     int32_t n = 0;
     int32_t cnt[KG_OI_BUFSZ] = {0, 0, 0, 0, 0}, oi[KG_OI_BUFSZ] = {0, 0, 0, 0, 0};
+    if (otu_init) {                                                     // the caller's oICounts (kg_aggregate_hits)
+        const kg_otu r0 = otu_init[s];
+        n = min(max(r0.n, 0), KG_OI_BUFSZ);
+#pragma unroll
+        for (int k = 0; k < KG_OI_BUFSZ; k++) { cnt[k] = r0.count[k]; oi[k] = r0.oI[k]; }
+    }
     const int64_t c0 = ccs[(uint64_t)s * per], c1 = ccs[(uint64_t)(s + 1) * per];
     for (int64_t c = c0; c < c1; c++) {
         const int32_t fI = calls[c].fI;
@@ -373,6 +379,46 @@ __global__ __launch_bounds__(256) void otu_wave_kernel(const kg_hit *__restrict_
         otu[s] = r;
     }
     }
+}
+
+// processSetOfHits (KGJ:385-455) on one caller-supplied list, as the public method of the reference class does it:
+// one lane walks the list (the method is a single step of gatherHits' state machine; kg_process_set_of_hits).
+// out[0] = 1 if a CALL was made, out[1] = the returned currentFI, out[2] = 1 if the list keeps its last two members.
+__global__ void process_set_single_kernel(const kg_hit *__restrict__ hits, int32_t n, int32_t current_fi, AggParams p,
+                                          kg_otu *otu, kg_call *call, int32_t *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int32_t count = 0, last = 0;
+    float wt = 0.f;
+    for (int32_t i = 0; i < n; i++)                                        // KGJ:390-396
+        if (hits[i].fI == current_fi) { last = i; count++; wt += hits[i].functionWt; }
+    int32_t called = 0;
+    kg_otu o = *otu;
+    if (count >= p.min_hits && wt >= (float)p.min_weighted_hits) {         // KGJ:397
+        called = 1;
+        kg_call c;
+        c.container = hits[0].container; c.start = hits[0].from0InProt; c.end = hits[last].from0InProt + (KG_K - 1);
+        c.count = count; c.fI = current_fi; c.weightedHits = wt;
+        *call = c;
+        for (int32_t i = 0; i <= last; i++) {                              // KGJ:413-439
+            if (hits[i].fI != current_fi) continue;
+            int32_t j = 0;
+            while (j < o.n && o.oI[j] != hits[i].oI) j++;
+            if (j == o.n) {
+                if (o.n == KG_OI_BUFSZ) j--; else o.n++;
+                o.oI[j] = hits[i].oI; o.count[j] = 1;
+            } else o.count[j]++;
+            while (j > 0 && o.count[j - 1] <= o.count[j]) {
+                const int32_t tc = o.count[j - 1], to = o.oI[j - 1];
+                o.count[j - 1] = o.count[j]; o.oI[j - 1] = o.oI[j];
+                o.count[j] = tc; o.oI[j] = to;
+                j--;
+            }
+        }
+    }
+    *otu = o;
+    const bool keep2 = hits[n - 2].fI != current_fi && hits[n - 2].fI == hits[n - 1].fI;      // KGJ:441-449
+    out[0] = called; out[1] = keep2 ? hits[n - 1].fI : current_fi; out[2] = keep2 ? 1 : 0;
 }
 
 }  // namespace kg

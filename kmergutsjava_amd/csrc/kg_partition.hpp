@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
         }
     };
 
-    unsigned long long n_valid = 0;
+    uint32_t n_valid = 0;                             // per lane: <= 6 x the wave's blocks
     bool ran_off = false;
     const uint32_t n_iter = (n_blocks + n_wg * kScatterWaves - 1) / (n_wg * kScatterWaves);
     // the next block's descriptor and characters are fetched while the current block is encoded
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
         const uint32_t it = (iter * n_wg + w) * kScatterWaves + (uint32_t)wave;      // wave-uniform
         uint64_t e[ROWS];
         uint32_t bk[ROWS];
-        uint32_t pend = 0, n_valid_block = 0;
+        uint32_t pend = 0, vmask = 0;
         if (it < n_blocks) {
             const BlockDesc bd = bd_next;
             uint32_t raw[4] = {raw_next[0], raw_next[1], raw_next[2], raw_next[3]};
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 uint32_t hi, lo, q;
                 bool valid = row_halves<AA>(l, r, lane, bd, &hi, &lo);
                 const uint32_t slot = split_fast(hi, lo, num_sigs, m35, &q);
-                if (valid) { n_valid++; n_valid_block++; }              // query k-mers (KGJ:913-920)
+                if (valid) vmask |= 1u << r;                            // query k-mers (KGJ:913-920), counted per block below
                 if (valid && slot >= limit32) ran_off = true;           // (truncated table file)
                 valid = valid && slot < limit32;                        // beyond the stream: never probed
                 bk[r] = slot >> shift;
@@ -183,12 +183,13 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                     const uint32_t lead0 = (uint32_t)__builtin_amdgcn_readlane((int)bk[0], __builtin_ctzll(m0));
                     if (__popcll(__ballot((pend & 1u) && bk[0] == lead0)) >= 24) {
                         if (lane == 0) lowc_blocks[atomicAdd(lowc_cursor, 1u)] = block_lo + it;
-                        n_valid -= n_valid_block;                          // counted again by lowc_blocks_kernel
+                        vmask = 0;                                         // counted by lowc_blocks_kernel
                         pend = 0;
                     }
                 }
             }
         }
+        n_valid += (uint32_t)__popc(vmask);
         // Insert without workgroup barriers.  A bucket's buffer is a 16-entry group with two counters:
         //   cnt[b]      tickets: atomicAdd gives the entry's place; >= 16 means "full, try again"
         //   written[b]  stores issued; the lane whose increment makes it 16 owns the group: it (with seven helper
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) fill[(uint64_t)b * n_wg + w] = wrel[b];
     for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off);
-    if (lane == 0 && n_valid) atomicAdd(&ctr[0], n_valid);
+    if (lane == 0 && n_valid) atomicAdd(&ctr[0], (unsigned long long)n_valid);
     flush_ran_off(ran_off, ctr, lane);
 }
 
@@ -318,15 +319,17 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
 // one piece (padded to whole groups with fillers; regions are filled through fill[] with global atomics now -- the
 // scatter workgroups have published them), or to the overflow list when the region is full; what is left goes in
 // single entries.  Regions are picked by block number, so a long run spreads over all of a bucket's regions.
+constexpr int kLowcWaves = 1;     // one wave per workgroup: 4.9 KB of LDS, so that the (usually idle) kernel finds room on a CU
+                                  // whose LDS a resident scatter workgroup has taken all but 7 KB of
 template <bool AA>
-__global__ __launch_bounds__(256) void lowc_blocks_kernel(
+__global__ __launch_bounds__(64 * kLowcWaves) void lowc_blocks_kernel(
     const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, const uint32_t *__restrict__ lowc_cursor,
     const uint32_t *__restrict__ lowc_blocks, uint64_t limit, uint32_t num_sigs, uint32_t m35, uint32_t shift, uint32_t n_regions,
     uint32_t cap, uint64_t *__restrict__ ent, uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap,
     uint32_t *__restrict__ ovf_bucket, uint64_t *__restrict__ ovf_ent, unsigned long long *ctr)
 {
     constexpr int ROWS = AA ? 1 : 6;
-    __shared__ typename WaveLds<AA>::type lds[4];
+    __shared__ typename WaveLds<AA>::type lds[kLowcWaves];
     __shared__ typename WaveLds<AA>::tables enc_tables;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     typename WaveLds<AA>::type &l = lds[wave];
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256) void lowc_blocks_kernel(
         if ((uint32_t)lane < ng) ovf_bucket[g + lane] = lead;
         return ovf_ent + (uint64_t)g * kGroup;
     };
-    for (uint32_t i = blockIdx.x * 4 + (uint32_t)wave; i < n_list; i += gridDim.x * 4) {
+    for (uint32_t i = blockIdx.x * kLowcWaves + (uint32_t)wave; i < n_list; i += gridDim.x * kLowcWaves) {
         const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)lowc_blocks[i]);
         const BlockDesc bd = blocks[it];
         encode_block<AA>(l, enc_tables, seq, bd, lane);

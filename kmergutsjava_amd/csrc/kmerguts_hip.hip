@@ -185,6 +185,7 @@ struct kg_table {
 
 struct kg_result {
     kg_table *tab = nullptr;
+    bool own_tab = false;        // kg_aggregate_hits: the result owns a table-less context (stream + block caches)
     kg_stats st = {};
     uint32_t per = 6;
     // device
@@ -536,6 +537,7 @@ void kg_result_free(kg_result *r)
     }
     for (void *h : {r->h_hits, r->h_chs, r->h_ccs, r->h_calls, r->h_otu, r->h_ev, r->h_tail_ev})
         if (h) { if (t) t->pins.put(h); else (void)hipHostFree(h); }
+    if (t && r->own_tab) kg_table_close(t);
     delete r;
 }
 
@@ -579,6 +581,59 @@ struct Scratch {
         return KG_OK;
     }
 };
+
+// gatherHits / processSetOfHits / the OTU buffer (KGJ:385-524) over res->d_hits + res->d_chs: fills the CALL, OTU and event
+// arrays of res.  d_partial: prefix-sum scratch for n_cont items, d_totals[4]: the CALL total.  otu_init (device, one record
+// per sequence, or null): the oICounts buffers the sequences start with (kg_aggregate_hits; the scan starts them empty).
+int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc, int64_t n_seqs, uint64_t n_cont, uint64_t n_hits,
+                    uint32_t PER, uint64_t *d_partial, uint64_t *d_totals, const kg_otu *d_otu_init, uint64_t *n_calls_out)
+{
+    int rc;
+    uint64_t n_calls = 0;
+    {
+        kg::AggParams ap;
+        ap.min_hits = p->min_hits; ap.min_weighted_hits = p->min_weighted_hits;
+        ap.max_gap = p->max_gap; ap.order_constraint = p->order_constraint ? 1 : 0;
+        uint32_t *d_ccnt = nullptr, *d_coff = nullptr; kg::CallSpan *d_spans = nullptr;
+        if ((rc = dalloc(t, (void **)&res->d_ev, n_hits))) return rc;
+        if ((rc = dalloc(t, (void **)&res->d_tail_ev, n_cont))) return rc;
+        uint8_t *d_acc = res->d_ev;
+        if ((rc = sc.get(&d_ccnt, n_cont))) return rc;
+        if ((rc = sc.get(&d_coff, n_cont))) return rc;
+        if ((rc = dalloc(t, (void **)&res->d_ccs, (n_cont + 1) * 8))) return rc;
+        if ((rc = dalloc(t, (void **)&res->d_otu, (size_t)(n_seqs ? n_seqs : 1) * sizeof(kg_otu)))) return rc;
+        // one wave per container; several consecutive containers per wave when there are millions of them (short reads)
+        const uint32_t cpw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, n_cont / (1u << 17)));
+        uint32_t cgrid = (uint32_t)(((n_cont + cpw - 1) / cpw + 3) / 4);
+        if (n_cont) {
+            hipLaunchKernelGGL((kg::calls_wave_kernel<false>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
+                               (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, (const uint32_t *)nullptr, (kg_call *)nullptr,
+                               (kg::CallSpan *)nullptr, cpw);
+            HIP_TRY(hipGetLastError());
+        }
+        if ((rc = prefix_sum(t, d_ccnt, n_cont, d_coff, d_partial, d_totals + 4))) return rc;
+        uint64_t h_calls = 0;
+        HIP_TRY(hipMemcpyAsync(&h_calls, d_totals + 4, 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        n_calls = n_cont ? h_calls : 0;
+        if ((rc = dalloc(t, (void **)&res->d_calls, n_calls * sizeof(kg_call)))) return rc;
+        if ((rc = sc.get(&d_spans, n_calls))) return rc;
+        if (n_cont && n_calls) {
+            hipLaunchKernelGGL((kg::calls_wave_kernel<true>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
+                               (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, d_coff, res->d_calls, d_spans, cpw);
+        }
+        hipLaunchKernelGGL(kg::call_starts_kernel, dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream, d_coff,
+                           n_cont, d_totals + 4, res->d_ccs);
+        if (n_seqs) {
+            const uint32_t spw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (uint64_t)n_seqs / (1u << 17)));
+            hipLaunchKernelGGL(kg::otu_wave_kernel, dim3((uint32_t)((((uint64_t)n_seqs + spw - 1) / spw + 3) / 4)), dim3(256), 0, t->stream,
+                               res->d_hits, d_acc, res->d_calls, d_spans, res->d_ccs, (uint32_t)n_seqs, PER, res->d_otu, spw, d_otu_init);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    *n_calls_out = n_calls;
+    return KG_OK;
+}
 
 template <bool AA>
 int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8_t *h_seq /* host copy still to upload, or null */,
@@ -704,8 +759,22 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         std::vector<uint64_t> clo;                                                    // chunk c = blocks [clo[c], clo[c+1])
         std::vector<int64_t> cseq;                                                    //         = sequences [cseq[c], cseq[c+1])
         clo.push_back(0); cseq.push_back(0);
+        // KG_PART_TAPER="30,30,25,15": chunk sizes in percent instead of equal chunks (tuning aid)
+        std::vector<double> cum;
+        if (const char *tp = getenv("KG_PART_TAPER")) {
+            double acc = 0;
+            for (const char *q = tp; *q;) {
+                char *endp = nullptr;
+                const double v = strtod(q, &endp);
+                if (endp == q) break;
+                acc += v; cum.push_back(acc);
+                q = *endp == ',' ? endp + 1 : endp;
+            }
+            if (cum.size() >= 2 && cum.size() <= kMaxChunks && acc > 0) { for (auto &x : cum) x /= acc; want = (uint32_t)cum.size(); }
+            else cum.clear();
+        }
         for (uint32_t c = 1; c < want; c++) {
-            const uint64_t target = nblocks * c / want;
+            const uint64_t target = cum.empty() ? nblocks * c / want : (uint64_t)((double)nblocks * cum[c - 1]);
             const auto it = std::lower_bound(ibase.begin(), ibase.end(), (uint32_t)target);        // a sequence start
             const uint64_t cut = *it;
             if (cut > clo.back() && cut < nblocks) { clo.push_back(cut); cseq.push_back((int64_t)(it - ibase.begin())); }
@@ -750,7 +819,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
         const size_t lds = kg::scatter_lds_bytes<AA>(part_buckets);
         HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 8u) & ~7u;
+        // 4 tag workgroups (16 waves) per CU: leaves the 16 wave slots a scatter workgroup of the next chunk needs, so the
+        // two passes really share the CUs; with 8 (all 32 slots) the scatter pass queues behind the persistent tag
+        // workgroups (profiles/r02_pipeline.md: 20.8 -> 20.4 ms per Gbp)
+        const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 4u) & ~7u;
         const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
         // per-chunk lists: hits (unordered) and candidates = fingerprint matches (hits + ~0.4 % of the probes) + the
         // ~2 % of the probes whose first tag window decides nothing
@@ -805,9 +877,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
                 hipStream_t s2 = t->stream2, s3 = t->stream3;
                 // the low-complexity blocks the scatter pass set aside (usually none: every workgroup reads the count and
-                // leaves).  In front of the chunk's tag pass, not behind its scatter pass: the scatter stream goes straight
-                // on to the next chunk instead of waiting for 512 workgroups to find room beside the resident tag kernel.
-                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(512), dim3(256), 0, s2, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
+                // leaves).  In front of the chunk's tag pass, not behind its scatter pass, and in one-wave workgroups whose
+                // 4.9 KB of LDS fit beside a resident scatter workgroup (153 KB of a CU's 160): with four-wave workgroups
+                // (15.8 KB) the kernel -- and the tag pass behind it -- waited for the NEXT chunk's scatter pass to leave
+                // the CUs (profiles/r02_pipeline.md).
+                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(2048 / kg::kLowcWaves), dim3(64 * kg::kLowcWaves), 0, s2, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
                                    t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
                                    ovf_bucket_c, ovf_ent_c, d_ctr);
 #define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
@@ -988,47 +1062,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
 
     // ---- aggregation: CALL records and OTU votes ----
     uint64_t n_calls = 0;
-    if (!(p->flags & KG_F_SKIP_AGGREGATE)) {
-        kg::AggParams ap;
-        ap.min_hits = p->min_hits; ap.min_weighted_hits = p->min_weighted_hits;
-        ap.max_gap = p->max_gap; ap.order_constraint = p->order_constraint ? 1 : 0;
-        uint32_t *d_ccnt = nullptr, *d_coff = nullptr; kg::CallSpan *d_spans = nullptr;
-        if ((rc = dalloc(t, (void **)&res->d_ev, n_hits))) return rc;
-        if ((rc = dalloc(t, (void **)&res->d_tail_ev, n_cont))) return rc;
-        uint8_t *d_acc = res->d_ev;
-        if ((rc = sc.get(&d_ccnt, n_cont))) return rc;
-        if ((rc = sc.get(&d_coff, n_cont))) return rc;
-        if ((rc = dalloc(t, (void **)&res->d_ccs, (n_cont + 1) * 8))) return rc;
-        if ((rc = dalloc(t, (void **)&res->d_otu, (size_t)(n_seqs ? n_seqs : 1) * sizeof(kg_otu)))) return rc;
-        // one wave per container; several consecutive containers per wave when there are millions of them (short reads)
-        const uint32_t cpw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, n_cont / (1u << 17)));
-        uint32_t cgrid = (uint32_t)(((n_cont + cpw - 1) / cpw + 3) / 4);
-        if (n_cont) {
-            hipLaunchKernelGGL((kg::calls_wave_kernel<false>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
-                               (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, (const uint32_t *)nullptr, (kg_call *)nullptr,
-                               (kg::CallSpan *)nullptr, cpw);
-            HIP_TRY(hipGetLastError());
-        }
-        if ((rc = prefix_sum(t, d_ccnt, n_cont, d_coff, d_partial, d_totals + 4))) return rc;
-        uint64_t h_calls = 0;
-        HIP_TRY(hipMemcpyAsync(&h_calls, d_totals + 4, 8, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        n_calls = n_cont ? h_calls : 0;
-        if ((rc = dalloc(t, (void **)&res->d_calls, n_calls * sizeof(kg_call)))) return rc;
-        if ((rc = sc.get(&d_spans, n_calls))) return rc;
-        if (n_cont && n_calls) {
-            hipLaunchKernelGGL((kg::calls_wave_kernel<true>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
-                               (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, d_coff, res->d_calls, d_spans, cpw);
-        }
-        hipLaunchKernelGGL(kg::call_starts_kernel, dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream, d_coff,
-                           n_cont, d_totals + 4, res->d_ccs);
-        if (n_seqs) {
-            const uint32_t spw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (uint64_t)n_seqs / (1u << 17)));
-            hipLaunchKernelGGL(kg::otu_wave_kernel, dim3((uint32_t)((((uint64_t)n_seqs + spw - 1) / spw + 3) / 4)), dim3(256), 0, t->stream,
-                               res->d_hits, d_acc, res->d_calls, d_spans, res->d_ccs, (uint32_t)n_seqs, PER, res->d_otu, spw);
-        }
-        HIP_TRY(hipGetLastError());
-    }
+    if (!(p->flags & KG_F_SKIP_AGGREGATE))
+        if ((rc = aggregate_stage(t, p, res, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, nullptr, &n_calls))) return rc;
     st.n_calls = (int64_t)n_calls;
     HIP_TRY(hipEventRecord(t->ev[4], t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
@@ -1114,6 +1149,94 @@ int kg_scan_device(kg_table *t, const kg_params *p, const uint8_t *d_seq, const 
                    kg_result **out)
 {
     return scan_entry(t, p, d_seq, true, offsets, n_seqs, out);
+}
+
+int kg_aggregate_hits(int device, const kg_params *p, const kg_hit *hits, const int64_t *container_hit_start, int64_t n_seqs,
+                      const kg_otu *otu_init, kg_result **out)
+{
+    if (!p || !container_hit_start || !out || n_seqs < 0) return fail(KG_ERR_ARG, "null or negative argument");
+    if (n_seqs > 0x7FFFFFF0ll / 6) return fail(KG_ERR_LIMIT, "too many sequences in one batch");
+    if (p->min_hits < 2)
+        return fail(KG_ERR_UNSUPPORTED, "minHits < 2: the reference throws in processSetOfHits (KGJ:442); refusing");
+    const uint32_t PER = p->aa ? 1u : 6u;
+    const uint64_t n_cont = (uint64_t)n_seqs * PER;
+    if (container_hit_start[0] != 0) return fail(KG_ERR_ARG, "container_hit_start[0] must be 0");
+    for (uint64_t c = 0; c < n_cont; c++)
+        if (container_hit_start[c + 1] < container_hit_start[c]) return fail(KG_ERR_ARG, "container_hit_start must be non-decreasing");
+    const uint64_t n_hits = (uint64_t)container_hit_start[n_cont];
+    if (n_hits && !hits) return fail(KG_ERR_ARG, "null hit records");
+    if (n_hits > 0xFFFFFF00ull) return fail(KG_ERR_LIMIT, "more than 2^32-256 hit records");
+    kg_table *t = nullptr;
+    int rc = table_new(device, &t);
+    if (rc) return rc;
+    kg_result *r = new (std::nothrow) kg_result();
+    if (!r) { kg_table_close(t); return fail(KG_ERR_NOMEM, "out of host memory"); }
+    r->tab = t; r->own_tab = true; r->per = PER;
+    rc = [&]() -> int {                 // (the scratch blocks go back to the context's cache before the context can be closed)
+        Scratch sc(t);
+        int rc2;
+        uint64_t *d_partial = nullptr, *d_totals = nullptr;
+        kg_otu *d_init = nullptr;
+        if ((rc2 = dalloc(t, (void **)&r->d_hits, (n_hits ? n_hits : 1) * sizeof(kg_hit)))) return rc2;
+        if ((rc2 = dalloc(t, (void **)&r->d_chs, (n_cont + 1) * 8))) return rc2;
+        if ((rc2 = sc.get(&d_partial, (size_t)(n_cont / kg::kScanChunk + 2)))) return rc2;
+        if ((rc2 = sc.get(&d_totals, 8))) return rc2;
+        if (otu_init && n_seqs && (rc2 = sc.get(&d_init, (size_t)n_seqs))) return rc2;
+        HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
+        if (n_hits) HIP_TRY(hipMemcpyAsync(r->d_hits, hits, n_hits * sizeof(kg_hit), hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(r->d_chs, container_hit_start, (n_cont + 1) * 8, hipMemcpyHostToDevice, t->stream));
+        if (d_init) HIP_TRY(hipMemcpyAsync(d_init, otu_init, (size_t)n_seqs * sizeof(kg_otu), hipMemcpyHostToDevice, t->stream));
+        uint64_t n_calls = 0;
+        if ((rc2 = aggregate_stage(t, p, r, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, d_init, &n_calls))) return rc2;
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        r->st.n_seqs = n_seqs; r->st.n_containers = (int64_t)n_cont; r->st.n_hits = (int64_t)n_hits; r->st.n_calls = (int64_t)n_calls;
+        r->st.windows_valid = -1; r->st.slots_inspected = -1;
+        return KG_OK;
+    }();
+    if (rc != KG_OK) { std::string keep = g_err; kg_result_free(r); g_err = keep; return rc; }
+    *out = r;
+    return KG_OK;
+}
+
+int kg_process_set_of_hits(int device, const kg_params *p, const kg_hit *hits, int32_t n_hits, int32_t current_fi, kg_otu *otu,
+                           kg_call *call, int32_t *called, int32_t *new_current_fi, int32_t *keeps_last_two)
+{
+    if (!p || !hits || !otu || !call || !called || !new_current_fi || !keeps_last_two) return fail(KG_ERR_ARG, "null argument");
+    if (n_hits < 2)
+        return fail(KG_ERR_UNSUPPORTED, "processSetOfHits on fewer than two hits: the reference throws (hits.get(numHits-2), KGJ:442); refusing");
+    if (otu->n < 0 || otu->n > KG_OI_BUFSZ) return fail(KG_ERR_ARG, "oICounts holds more than OI_BUFSZ entries");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(KG_ERR_DEVICE, "no HIP device: libkmerguts_hip needs an MI355X (gfx950) GPU; there is no CPU path");
+    if (device < 0 || device >= ndev) return fail(KG_ERR_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    kg_hit *d_hits = nullptr;
+    uint8_t *d_small = nullptr;                        // kg_otu | kg_call | int32 x 4
+    const size_t small = sizeof(kg_otu) + sizeof(kg_call) + 16;
+    HIP_TRY(hipMalloc((void **)&d_hits, (size_t)n_hits * sizeof(kg_hit)));
+    hipError_t e = hipMalloc((void **)&d_small, small);
+    if (e == hipSuccess) e = hipMemcpy(d_hits, hits, (size_t)n_hits * sizeof(kg_hit), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_small, 0, small);
+    if (e == hipSuccess) e = hipMemcpy(d_small, otu, sizeof(kg_otu), hipMemcpyHostToDevice);
+    uint8_t h_small[sizeof(kg_otu) + sizeof(kg_call) + 16];
+    if (e == hipSuccess) {
+        kg::AggParams ap;
+        ap.min_hits = p->min_hits; ap.min_weighted_hits = p->min_weighted_hits;
+        ap.max_gap = p->max_gap; ap.order_constraint = p->order_constraint ? 1 : 0;
+        hipLaunchKernelGGL(kg::process_set_single_kernel, dim3(1), dim3(64), 0, nullptr, d_hits, n_hits, current_fi, ap,
+                           (kg_otu *)d_small, (kg_call *)(d_small + sizeof(kg_otu)), (int32_t *)(d_small + sizeof(kg_otu) + sizeof(kg_call)));
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(h_small, d_small, small, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_hits);
+    if (d_small) (void)hipFree(d_small);
+    if (e != hipSuccess) return fail(KG_ERR_DEVICE, std::string("processSetOfHits on the device failed: ") + hipGetErrorString(e));
+    memcpy(otu, h_small, sizeof(kg_otu));
+    memcpy(call, h_small + sizeof(kg_otu), sizeof(kg_call));
+    int32_t o3[4];
+    memcpy(o3, h_small + sizeof(kg_otu) + sizeof(kg_call), 16);
+    *called = o3[0]; *new_current_fi = o3[1]; *keeps_last_two = o3[2];
+    return KG_OK;
 }
 
 int kg_result_stats(const kg_result *r, kg_stats *out)

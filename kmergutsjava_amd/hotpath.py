@@ -87,17 +87,17 @@ class ScanResult:
         lib = self._need()
         return N.view(lib.kg_result_container_hit_start(self._h), self.stats["n_containers"] + 1, np.dtype("<i8"))
 
-    def calls(self) -> np.ndarray:
+    def calls(self, copy: bool = True) -> np.ndarray:
         lib = self._need()
-        return N.view(lib.kg_result_calls(self._h), self.stats["n_calls"], N.CALL_DTYPE)
+        return N.view(lib.kg_result_calls(self._h), self.stats["n_calls"], N.CALL_DTYPE, None if copy else self)
 
     def container_call_start(self) -> np.ndarray:
         lib = self._need()
         return N.view(lib.kg_result_container_call_start(self._h), self.stats["n_containers"] + 1, np.dtype("<i8"))
 
-    def otu(self) -> np.ndarray:
+    def otu(self, copy: bool = True) -> np.ndarray:
         lib = self._need()
-        return N.view(lib.kg_result_otu(self._h), self.stats["n_seqs"], N.OTU_DTYPE)
+        return N.view(lib.kg_result_otu(self._h), self.stats["n_seqs"], N.OTU_DTYPE, None if copy else self)
 
     def hit_events(self) -> np.ndarray:
         """One KG_EV_* byte per hit record: what gatherHits did there (for the -d stream)."""
@@ -180,6 +180,23 @@ class ScanResult:
             self.close()
         except Exception:
             pass
+
+
+def aggregate_hits(hits: np.ndarray, container_hit_start, n_seqs: int, params: Optional[Params] = None,
+                   otu_init: Optional[np.ndarray] = None, device: int = 0) -> ScanResult:
+    """gatherHits / processSetOfHits / the OTU buffer (KGJ:385-524) on the GPU over caller-held hit records (HIT_DTYPE,
+    ordered by container and from0InProt).  otu_init: OTU_DTYPE[n_seqs], the oICounts buffers to start from."""
+    params = params or Params()
+    p = params.to_native()
+    h = np.ascontiguousarray(hits, dtype=N.HIT_DTYPE)
+    chs = np.ascontiguousarray(np.asarray(container_hit_start, dtype=np.int64))
+    if chs.size != n_seqs * (1 if params.aa else 6) + 1:
+        raise ValueError("container_hit_start must have n_seqs * (1 or 6) + 1 entries")
+    init = None if otu_init is None else np.ascontiguousarray(otu_init, dtype=N.OTU_DTYPE)
+    out = C.c_void_p()
+    N.check(N.load().kg_aggregate_hits(device, C.byref(p), h.ctypes.data if h.size else None, chs.ctypes.data, n_seqs,
+                                       init.ctypes.data if init is not None and init.size else None, C.byref(out)))
+    return ScanResult(out.value)
 
 
 class SignatureTable:
