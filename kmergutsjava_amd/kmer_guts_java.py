@@ -205,7 +205,77 @@ def _resident_table(path: str, device: int) -> SignatureTable:
     return tab
 
 
+class Hit:
+    """KGJ:1213-1219"""
+    __slots__ = ("oI", "from0InProt", "avgOffFromEnd", "fI", "functionWt")
+
+    def __init__(self, oI=0, from0InProt=0, avgOffFromEnd=0, fI=0, functionWt=0.0):
+        self.oI, self.from0InProt, self.avgOffFromEnd, self.fI, self.functionWt = oI, from0InProt, avgOffFromEnd, fI, functionWt
+
+
+class OtuCount:
+    """KGJ:1221-1224"""
+    __slots__ = ("oI", "count")
+
+    def __init__(self, oI=0, count=0):
+        self.oI, self.count = oI, count
+
+
+class HitContainerKey:
+    """KGJ:1226-1260: equality and hash over (queryId, strand, frame)."""
+    __slots__ = ("queryId", "strand", "frame")
+
+    def __init__(self, queryId=None, strand="+", frame=0):
+        self.queryId, self.strand, self.frame = queryId, strand, frame
+
+    def __eq__(self, other):
+        return (isinstance(other, HitContainerKey) and self.frame == other.frame and self.queryId == other.queryId
+                and self.strand == other.strand)
+
+    def __hash__(self):
+        return hash((self.queryId, self.strand, self.frame))
+
+
+class HitContainer:
+    """KGJ:1262-1266"""
+    __slots__ = ("key", "id", "hits")
+
+    def __init__(self, key=None, id=0, hits=None):
+        self.key, self.id, self.hits = key, id, [] if hits is None else hits
+
+
+class QueryKmer:
+    """KGJ:1200-1204"""
+    __slots__ = ("value", "hitCntId", "protPos")
+
+    def __init__(self, value=0, hitCntId=0, protPos=0):
+        self.value, self.hitCntId, self.protPos = value, hitCntId, protPos
+
+
+def _hits_to_records(hits, container: int = 0) -> np.ndarray:
+    rec = np.zeros(len(hits), dtype=N.HIT_DTYPE)
+    for i, h in enumerate(hits):
+        rec[i] = (container, h.from0InProt, h.oI, h.avgOffFromEnd, h.fI, h.functionWt)
+    return rec
+
+
+def _otu_to_record(oICounts) -> np.ndarray:
+    rec = np.zeros(1, dtype=N.OTU_DTYPE)
+    if len(oICounts) > KmerGutsJava.OI_BUFSZ:
+        raise ValueError("oICounts holds more than OI_BUFSZ entries")
+    rec["n"][0] = len(oICounts)
+    for j, oc in enumerate(oICounts):
+        rec["oI"][0][j], rec["count"][0][j] = oc.oI, oc.count
+    return rec
+
+
+def _record_to_otu(rec, oICounts) -> None:
+    oICounts[:] = [OtuCount(int(rec["oI"][j]), int(rec["count"][j])) for j in range(int(rec["n"]))]
+
+
 class KmerGutsJava:
+    Hit, OtuCount, HitContainerKey, HitContainer, QueryKmer = Hit, OtuCount, HitContainerKey, HitContainer, QueryKmer
+
     # KGJ:85-99
     K = 8
     CORE = 20 ** 7
@@ -262,6 +332,63 @@ class KmerGutsJava:
     @staticmethod
     def dnaChar(c: str) -> int:
         return {"a": 0, "A": 0, "c": 1, "C": 1, "g": 2, "G": 2, "t": 3, "u": 3, "T": 3, "U": 3}.get(c, 4)
+
+    # ---- the public instance methods of the reference class (KGJ:385, 457, 526, 1082), on the GPU through the C ABI ----
+    def _params(self) -> Params:
+        return Params(aa=True, order_constraint=self.orderConstraint, min_hits=self.minHits,
+                      min_weighted_hits=self.minWeightedHits, max_gap=self.maxGap)
+
+    def processSetOfHits(self, hits: list, functionArray, currentFI: int, oICounts: list, pw) -> int:
+        """KGJ:385-455: one step of the state machine on the caller's list; prints the CALL (and, with debug, the
+        after-call line), updates oICounts, keeps the last two hits or empties the list, returns the new currentFI."""
+        import ctypes as C
+        if len(hits) < 2:
+            raise IndexError("Index: %d, Size: %d" % (len(hits) - 2, len(hits)))      # hits.get(numHits - 2) throws
+        rec = _hits_to_records(hits)
+        otu = _otu_to_record(oICounts)
+        call = np.zeros(1, dtype=N.CALL_DTYPE)
+        called, new_fi, keep2 = C.c_int32(), C.c_int32(), C.c_int32()
+        p = self._params().to_native()
+        N.check(N.load().kg_process_set_of_hits(self.device, C.byref(p), rec.ctypes.data, len(rec), int(currentFI),
+                                                 otu.ctypes.data, call.ctypes.data, C.byref(called), C.byref(new_fi), C.byref(keep2)))
+        if called.value:
+            self._print_call(call[0], functionArray, pw.write)
+            if self.debug:                                                          # KGJ:406-409
+                pw.write("after-call: hits: " + "".join("%d/%s/%d " % (h.from0InProt, java_format_f(h.functionWt), h.fI) for h in hits) + "\n")
+        _record_to_otu(otu[0], oICounts)
+        hits[:] = hits[-2:] if keep2.value else []
+        return int(new_fi.value)
+
+    def gatherHits(self, ln_DNA: int, strand: str, frame: int, allHits: list, functionArray, oICounts: list, pw) -> None:
+        """KGJ:457-514: sorts allHits by from0InProt (in place, stable), runs the run / vote state machine over them,
+        prints the CALL lines (the whole -d stream with debug) and carries the OTU buffer oICounts on."""
+        from .hotpath import aggregate_hits
+        allHits.sort(key=lambda h: h.from0InProt)                                   # Collections.sort is stable (KGJ:460-465)
+        rec = _hits_to_records(allHits)
+        with aggregate_hits(rec, [0, len(rec)], 1, self._params(), _otu_to_record(oICounts), self.device) as r:
+            calls, otu = r.calls(), r.otu()
+            if self.debug:
+                self._print_debug_stream(calls, functionArray, pw.write, rec, r.hit_events(), int(r.container_tail_events()[0]))
+            else:
+                self._print_calls(calls, functionArray, pw.write)
+        _record_to_otu(otu[0], oICounts)
+
+    def processAASeq(self, id: str, proteinLen: int, hitCnts: dict, functionArray, pw) -> None:
+        """KGJ:526-536"""
+        oICounts: list = []
+        pw.write("PROTEIN-ID\t%s\t%d\n" % (id, proteinLen))
+        self.gatherHits(proteinLen, "+", 0, hitCnts[HitContainerKey(id, "+", 0)].hits, functionArray, oICounts, pw)
+        pw.write("OTU-COUNTS\t%s[%d]" % (id, proteinLen) + "".join("\t%d-%d" % (oc.count, oc.oI) for oc in oICounts) + "\n")   # KGJ:516-524
+
+    @staticmethod
+    def createKmerComparator(numSigs: int):
+        """KGJ:1082-1095: orders QueryKmer objects by (value % numSigs, value); a cmp function (functools.cmp_to_key)."""
+        def compare(o1, o2) -> int:
+            h1, h2 = o1.value % numSigs, o2.value % numSigs
+            if h1 != h2:
+                return -1 if h1 < h2 else 1
+            return (o1.value > o2.value) - (o1.value < o2.value)
+        return compare
 
     # ---- KmerGutsJavaServer.status (KmerGutsJavaServer.java:33-45) ----
     def status(self) -> dict:

@@ -36,7 +36,8 @@ for k in scan_kernels:
         continue
     tot_fetch += sum(f[k]["FETCH_SIZE"]) / scans * (2 if (strategy == "direct" and len(f[k]["FETCH_SIZE"]) == 1) else 1)
     tot_write += sum(w[k]["WRITE_SIZE"]) / scans * (2 if (strategy == "direct" and len(w[k]["WRITE_SIZE"]) == 1) else 1)
-out = {"round": rnd, "total_bp": bench["config"]["total_bp_per_gpu"], "num_sigs": bench["config"]["num_sigs"], "strategy": strategy,
+out = {"round": rnd, "total_bp": bench["config"].get("total_bp_rank0", bench["config"].get("total_bp_per_gpu")),
+       "num_sigs": bench["config"]["num_sigs"], "strategy": strategy,
        "scan_stage_kernels": scan_kernels, "FETCH_SIZE_KB_per_scan": tot_fetch, "WRITE_SIZE_KB_per_scan": tot_write,
        "hbm_bytes_per_launch": (2 * tot_fetch + tot_write) * 1024,
        "correction": "gfx950: FETCH_SIZE tallies every TCC_EA0_RDREQ at 64 B but the requests are 128-B lines (MI355X_MICROARCH.md 'HBM': "
