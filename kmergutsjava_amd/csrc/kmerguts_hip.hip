@@ -178,6 +178,7 @@ struct kg_table {
     uint32_t m35 = 0;            // floor(2^35 / num_sigs) when 64 <= num_sigs < 2^31 (kg::split_fast), else 0
     uint64_t occupied = 0;
     double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
+    size_t scatter_lds[2] = {0, 0};  // dynamic LDS the scatter kernel (DNA / protein) has been allowed so far
     hipEvent_t ev[8] = {};
     DevCache cache;
     PinCache pins;
@@ -818,7 +819,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
         HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
         const size_t lds = kg::scatter_lds_bytes<AA>(part_buckets);
-        HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (t->scatter_lds[AA ? 1 : 0] < lds) {         // once per table (and geometry): the call costs tens of microseconds
+            HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            t->scatter_lds[AA ? 1 : 0] = lds;
+        }
         // 4 tag workgroups (16 waves) per CU: leaves the 16 wave slots a scatter workgroup of the next chunk needs, so the
         // two passes really share the CUs; with 8 (all 32 slots) the scatter pass queues behind the persistent tag
         // workgroups (profiles/r02_pipeline.md: 20.8 -> 20.4 ms per Gbp)
@@ -837,6 +841,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         bool too_skewed = false;
         const uint32_t grab_unit = 256u * kg::kProbeN;
         const uint32_t probe_grab = (std::max(env_u32("KG_PROBE_GRAB", cap), grab_unit) + grab_unit - 1) / grab_unit * grab_unit;
+        uint64_t h_tot[6] = {0, 0, 0, 0, 0, 0};
         HIP_TRY(hipEventRecord(t->ev[1], t->stream));
         for (int attempt = 0; attempt < 3; attempt++) {
             const uint64_t hits_cap = ucap * n_chunks_p;
@@ -928,8 +933,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             st.scan_launches++;
             uint64_t h_pc[48];
             uint32_t h_ovf[8 * kMaxChunks];
+            HIP_TRY(hipEventRecord(t->ev[2], t->stream));                 // end of the scan stage (of this attempt)
             HIP_TRY(hipMemcpyAsync(h_pc, d_pc, sizeof h_pc, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipMemcpyAsync(h_ovf, d_ovfc, sizeof h_ovf, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 48, hipMemcpyDeviceToHost, t->stream));   // one host round trip for all three
             HIP_TRY(hipStreamSynchronize(t->stream));
             uint64_t need_u = 0, need_c = 0;
             uint32_t max_ovf = 0, guard = 0;
@@ -963,10 +970,6 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             dfree(t, res->d_hits);
             res->d_hits = nullptr;
         } else {
-            HIP_TRY(hipEventRecord(t->ev[2], t->stream));
-            uint64_t h_tot[6] = {0, 0, 0, 0, 0, 0};
-            HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 48, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipStreamSynchronize(t->stream));
             st.windows_valid = counters ? (int64_t)h_tot[2] : -1;
             st.slots_inspected = counters ? (int64_t)h_tot[3] : -1;
             st.lookup_ran_off = h_tot[5] ? 1 : 0;
