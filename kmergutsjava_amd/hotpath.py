@@ -8,6 +8,7 @@ libkmerguts_hip.so on the GPU; this file only moves pointers.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -56,8 +57,9 @@ def device_tensor(ptr: int, count: int, typestr: str = "|u1", owner=None, device
 class ScanResult:
     """Owns one kg_result.  Record arrays are numpy structured arrays (copies)."""
 
-    def __init__(self, handle: int):
+    def __init__(self, handle: int, table=None):
         self._h = C.c_void_p(handle)
+        self._table = table              # a result must be freed before its table (kg_result_free uses the table's caches)
         st = N.KgStats()
         N.check(N.load().kg_result_stats(self._h, C.byref(st)))
         self.stats = st.as_dict()
@@ -205,6 +207,7 @@ class SignatureTable:
     def __init__(self, handle: int, keepalive=None):
         self._h = C.c_void_p(handle)
         self._keep = keepalive
+        self._results = weakref.WeakSet()      # results still open: closed with the table, before it
 
     @classmethod
     def open(cls, path: str, device: int = 0) -> "SignatureTable":
@@ -255,10 +258,14 @@ class SignatureTable:
                 raise ValueError("sequence buffer shorter than offsets[-1]")
             ptr = arr.ctypes.data if arr.size else None
             N.check(lib.kg_scan(self._h, C.byref(p), ptr, off.ctypes.data, n, C.byref(out)))
-        return ScanResult(out.value)
+        r = ScanResult(out.value, self)
+        self._results.add(r)
+        return r
 
     def close(self) -> None:
         if self._h:
+            for r in list(self._results):
+                r.close()
             N.load().kg_table_close(self._h)
             self._h = C.c_void_p(None)
             self._keep = None

@@ -184,3 +184,57 @@ def test_config5_high_density_full_size(hp, oracle, dna, monkeypatch):
             with tab.scan(None, off, hp.Params(aa=not dna), device_ptr=seq.data_ptr()) as rb:
                 assert rb.stats["partitioned"] != ra.stats["partitioned"] and rb.stats["fallback"] == 0, rb.stats
                 _same_on_device(ra, rb, "config 5 dna=%s, the two strategies" % dna)
+
+
+def test_sharded_scans_restored_on_the_device_equal_the_unsharded_scan(hp):
+    """The exchange step of the multi-GPU layer without a process group: the batch is cut into three shards of whole
+    contigs (distributed.shard_sequences), every shard is scanned on this GPU, the library's own HBM buffers are wrapped
+    as torch tensors (ScanResult.device_view: what travels over RCCL) and distributed.restore_hits puts the records in
+    global order on the device -- byte-identical to the hit array of the unsharded scan."""
+    from kmergutsjava_amd import synth, distributed as kd
+    dev = torch.device("cuda", 0)
+    rec, placed, keys = synth.random_table(30_000_019, 0.5, 77, dev)
+    del keys
+    lens = synth.contig_mix_lengths(40_000_000, 301)
+    off = synth.offsets_of(lens)
+    seq = synth.random_dna(int(off[-1]), 302, dev)
+    torch.cuda.synchronize()
+    with hp.SignatureTable.from_device_ptr(rec.data_ptr(), 30_000_019, 0, keepalive=rec) as tab:
+        with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as whole:
+            want_hits = whole.device_view("hits").clone()
+            want_chs = whole.device_view("container_hit_start").clone()
+        shards = kd.shard_sequences(lens, 3)
+        results, hits, chs, idx = [], [], [], []
+        for mine in shards:
+            s_lens = lens[mine]
+            s_off = synth.offsets_of(s_lens)
+            s_seq = synth.random_dna_at(off[mine], s_lens, 302, dev)          # the shard's contigs have the batch's bases
+            torch.cuda.synchronize()
+            r = tab.scan(None, s_off, hp.Params(), device_ptr=s_seq.data_ptr())
+            results.append(r)
+            hits.append(r.device_view("hits"))
+            chs.append(r.device_view("container_hit_start"))
+            idx.append(torch.as_tensor(mine, device=dev))
+            assert hits[-1].is_cuda and hits[-1].data_ptr() == r.device_hits_ptr()       # zero-copy
+        got_hits, got_chs = kd.restore_hits(hits, chs, idx, len(lens), 6)
+        assert got_hits.is_cuda
+        assert torch.equal(got_hits.contiguous().view(torch.uint8).reshape(-1), want_hits)
+        assert torch.equal(got_chs, want_chs)
+        assert int(want_chs[-1]) > 10_000
+        hits, chs = [], []
+        tab.close()                         # results still open: the table closes them first
+        assert all(r._h.value is None for r in results)
+
+
+def test_copy_hits_and_zero_copy_views(hp):
+    from kmergutsjava_amd import synth
+    seq, off, rec, keys = synth.high_density_config(40, 300, 200_003, 60_000, dna=True)
+    with hp.SignatureTable.from_bytes(synth.table_image(rec)) as tab, tab.scan(seq.numpy(), off, hp.Params(min_hits=2)) as r:
+        h = r.hits()
+        assert len(h) > 5_000
+        assert r.copy_hits().tobytes() == h.tobytes()
+        part = np.zeros(1000, dtype=h.dtype)
+        assert r.copy_hits(123, 1000, out=part).tobytes() == h[123:1123].tobytes()
+        assert r.calls(copy=False).tobytes() == r.calls().tobytes() and r.otu(copy=False).tobytes() == r.otu().tobytes()
+        with pytest.raises(Exception):
+            r.copy_hits(len(h) - 10, 11)
