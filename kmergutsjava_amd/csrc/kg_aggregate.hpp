@@ -16,10 +16,14 @@
 //   * processSetOfHits walks the list in 64-record chunks; the float32 weight sum is added in list
 //     order (KGJ:394) by visiting the voters' lanes in ascending order.
 //
-// Calls per container are counted first (EMIT = false), prefix-summed, then written (EMIT = true)
-// so that calls[] is in the reference's emission order without atomics.
+// One pass.  A container's CALL records go to its own range of a staging array: a hit votes for at most one CALL (after a
+// CALL the list is emptied or cut down to two members that did not vote) and a CALL needs >= minHits voters, so container c
+// makes at most hits_c / minHits CALLs and [chs[c] / minHits, chs[c + 1] / minHits) is room enough; the counts are
+// prefix-summed and compact_calls_kernel moves the records to calls[] in the reference's emission order, no atomics.
+// The pass also marks every record whose vote counted towards a CALL (vote[]): the OTU stage (KGJ:413-439) then is one
+// streaming walk over a sequence's records in order -- voters of successive CALLs have ascending indices.
 //
-// The counting pass also leaves one event byte per record (KG_EV_* in kmerguts_hip.h) and one per
+// The pass leaves one event byte per record (KG_EV_* in kmerguts_hip.h) and one per
 // container: what the machine did at that record (appended it, reset the list before / after it,
 // whether that reset printed a CALL and whether it kept the last two members).  Bit 0 is the
 // "accepted" byte above; the rest lets the host print the reference's -d stream (HIT / after-hit /
@@ -35,8 +39,6 @@ namespace kg {
 
 struct AggParams { int32_t min_hits, min_weighted_hits, max_gap, order_constraint; };
 
-struct CallSpan { uint32_t lo, last_hit; };   // global hit indices: first record of the called set, last voter
-
 struct AggState {                 // everything here is wave-uniform
     uint32_t lo, last, prev;      // hit indices of the list's first / last / second-to-last member
     int32_t last_pos, last_fI, last_avg, prev_fI;
@@ -50,13 +52,14 @@ __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_read
 
 // processSetOfHits (KGJ:385-455) on the list [s.lo .. s.last].  chunk grid is anchored at `begin`
 // so that the chunk the caller is working on (cur_base, membership bits cur_mask, the lanes' fI and
-// functionWt) is taken from registers instead of memory.
+// functionWt) is taken from registers instead of memory.  A CALL goes to calls[s.ncalls] (the container's staging
+// range); its voters are marked in vote[] -- those of the caller's chunk in cur_votes, which the caller stores with the
+// chunk's other bytes.
 // returns bit 0: a CALL was made, bit 1: the last two members were kept
-template <bool EMIT>
-__device__ __forceinline__ uint32_t process_set(const kg_hit *__restrict__ h, const uint8_t *__restrict__ acc, uint32_t begin,
-                                            const AggParams &p, AggState &s, uint32_t cur_base, uint64_t cur_mask,
-                                            int32_t cur_fI, float cur_wt, uint32_t container, uint32_t call_at, kg_call *calls,
-                                            CallSpan *spans, bool allow_carry)
+__device__ __forceinline__ uint32_t process_set(const kg_hit *__restrict__ h, const uint8_t *__restrict__ acc, uint8_t *__restrict__ vote,
+                                            uint32_t begin, const AggParams &p, AggState &s, uint32_t cur_base, uint64_t cur_mask,
+                                            int32_t cur_fI, float cur_wt, uint64_t &cur_votes, uint32_t container, kg_call *calls,
+                                            bool allow_carry)
 {
     const int lane = threadIdx.x & 63;
     int32_t fICount = 0;
@@ -93,17 +96,25 @@ __device__ __forceinline__ uint32_t process_set(const kg_hit *__restrict__ h, co
     uint32_t what = 0;
     if (fICount >= p.min_hits && weighted >= (float)p.min_weighted_hits) {      // KGJ:397
         what = 1;
-        if (EMIT && lane == 0) {
+        if (lane == 0) {
             kg_call c;
             c.container = container;
             c.start = h[s.lo].from0InProt;                              // KGJ:399: first record of the set, any fI
             c.end = h[lastHit].from0InProt + (KG_K - 1);                // KGJ:400
             c.count = fICount; c.fI = s.currentFI; c.weightedHits = weighted;
-            calls[call_at + s.ncalls] = c;
-            CallSpan sp; sp.lo = s.lo; sp.last_hit = lastHit;
-            spans[call_at + s.ncalls] = sp;
+            calls[s.ncalls] = c;
         }
         s.ncalls++;
+        // the voters (KGJ:413-415: members with fI == currentFI up to lastHit = all of them)
+        for (uint32_t b = c0; b <= s.last; b += 64) {
+            const uint32_t i = b + lane;
+            const bool in = i >= s.lo && i <= s.last;
+            if (b == cur_base) {
+                cur_votes |= __ballot(in && ((cur_mask >> lane) & 1ull) != 0 && cur_fI == s.currentFI);
+            } else if (in && (acc[i] & KG_EV_ACCEPTED) != 0 && h[i].fI == s.currentFI) {
+                vote[i] = 1;
+            }
+        }
     }
     // KGJ:441-453: keep the last two members if they open a new function, else clear
     if (allow_carry && s.cnt >= 2 && s.prev_fI != s.currentFI && s.prev_fI == s.last_fI) {
@@ -134,11 +145,10 @@ struct EvMasks {
     }
 };
 
-template <bool EMIT>
 __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restrict__ hits, const int64_t *__restrict__ chs,
-                                                         uint32_t n_cont, AggParams p, uint8_t *acc, uint8_t *tail_ev,
-                                                         uint32_t *call_cnt, const uint32_t *call_off, kg_call *calls,
-                                                         CallSpan *spans, uint32_t per_wave)
+                                                         uint32_t n_cont, AggParams p, uint8_t *acc, uint8_t *vote, uint8_t *tail_ev,
+                                                         uint32_t *call_cnt, kg_call *staged /* [n_hits / minHits + 1] */,
+                                                         uint32_t per_wave)
 {
     // per_wave consecutive containers per wave: 1 for few long containers (contigs); more for millions of short ones
     // (reads), where launching a wave per container would cost more than the work
@@ -150,19 +160,18 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
     uint32_t my_begin = 0, my_end = 0;
     const bool mine = (uint32_t)lane < per_wave && c_first + (uint32_t)lane < n_cont;
     if (mine) { my_begin = (uint32_t)chs[c_first + lane]; my_end = (uint32_t)chs[c_first + lane + 1]; }
-    if (!EMIT && mine && my_end - my_begin < 2) {
+    if (mine && my_end - my_begin < 2) {
         call_cnt[c_first + lane] = 0;
         tail_ev[c_first + lane] = 0;
-        if (my_end != my_begin) acc[my_begin] = (uint8_t)KG_EV_ACCEPTED;
+        if (my_end != my_begin) { acc[my_begin] = (uint8_t)KG_EV_ACCEPTED; vote[my_begin] = 0; }
     }
     uint64_t todo = __ballot(mine && my_end - my_begin >= 2);
     while (todo) {
     const int ci = __builtin_ctzll(todo);
     todo &= todo - 1;
     const uint32_t c = c_first + (uint32_t)ci;
-    if (EMIT && call_cnt[c] == 0) continue;        // nothing to write; acc[] was filled by the counting pass
     const uint32_t begin = (uint32_t)rl((int32_t)my_begin, ci), end = (uint32_t)rl((int32_t)my_end, ci);
-    const uint32_t call_at = EMIT ? call_off[c] : 0;
+    kg_call *calls = staged + begin / (uint32_t)p.min_hits;          // the container's staging range (see the header)
 
     AggState s;
     s.lo = s.last = s.prev = begin;
@@ -181,6 +190,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
         float wt = 0.f;
         if (lane < n) { pos = hits[i].from0InProt; fI = hits[i].fI; avg = hits[i].avgOffFromEnd; wt = hits[i].functionWt; }
         uint64_t accmask;
+        uint64_t votes = 0;                          // records of this chunk whose vote counted towards a CALL
         EvMasks em = {0, 0, 0, 0, 0, 0};
 
         // the fast path needs every record of the chunk to be accepted and the list's last member to be
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                         s.last = ik - 1;
                         // no carry is possible here: a pair of equal, non-current fI at the end of the list
                         // would have fired the pair rule when its second record was appended
-                        what = process_set<EMIT>(hits, acc, begin, p, s, base, accmask, fI, wt, c, call_at, calls, spans, false);
+                        what = process_set(hits, acc, vote, begin, p, s, base, accmask, fI, wt, votes, c, calls, false);
                     } else {
                         s.cnt = 0;
                     }
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                 s.cnt++;                                                                 // KGJ:496-497
                 if (s.cnt > 1 && s.currentFI != fk && ((eqm >> k) & 1)) {                // KGJ:503-508
                     s.last = ik; s.prev = ik - 1; s.last_fI = fk; s.prev_fI = fk;
-                    em.after(k, process_set<EMIT>(hits, acc, begin, p, s, base, accmask, fI, wt, c, call_at, calls, spans, true));
+                    em.after(k, process_set(hits, acc, vote, begin, p, s, base, accmask, fI, wt, votes, c, calls, true));
                 }
                 k0 = k + 1;
             }
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                 if (s.cnt > 0 && (int32_t)((uint32_t)s.last_pos + (uint32_t)p.max_gap) < pk) {      // KGJ:477-484
                     uint32_t what = 0;
                     if (s.cnt >= p.min_hits)
-                        what = process_set<EMIT>(hits, acc, begin, p, s, base, accmask, fI, wt, c, call_at, calls, spans, true);
+                        what = process_set(hits, acc, vote, begin, p, s, base, accmask, fI, wt, votes, c, calls, true);
                     else
                         s.cnt = 0;
                     em.before(k, what);
@@ -274,11 +284,11 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                         accmask |= 1ull << k;
                     }
                     if (s.cnt > 1 && s.currentFI != fk && s.prev_fI == s.last_fI)                    // KGJ:503-508
-                        em.after(k, process_set<EMIT>(hits, acc, begin, p, s, base, accmask, fI, wt, c, call_at, calls, spans, true));
+                        em.after(k, process_set(hits, acc, vote, begin, p, s, base, accmask, fI, wt, votes, c, calls, true));
                 }
             }
         }
-        if (!EMIT && lane < n) {
+        if (lane < n) {
             uint32_t e = (uint32_t)((accmask >> lane) & 1ull) * KG_EV_ACCEPTED;
             e |= (uint32_t)((em.pb >> lane) & 1ull) * KG_EV_RESET_BEFORE;
             e |= (uint32_t)((em.pb_call >> lane) & 1ull) * KG_EV_CALL_BEFORE;
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
             e |= (uint32_t)((em.pa_call >> lane) & 1ull) * KG_EV_CALL_AFTER;
             e |= (uint32_t)((em.pa_keep >> lane) & 1ull) * KG_EV_KEEP2_AFTER;
             acc[i] = (uint8_t)e;
+            vote[i] = (uint8_t)((votes >> lane) & 1ull);
         }
         carry_pos = rl(pos, n - 1);
         carry_fI = rl(fI, n - 1);
@@ -297,10 +308,28 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
     }
     uint32_t tail = 0;
     if (s.cnt >= p.min_hits) {                                                                       // KGJ:511-513
-        tail = process_set<EMIT>(hits, acc, begin, p, s, tail_base, tail_mask, tail_fI, tail_wt, c, call_at, calls, spans, true) & 1u;
+        uint64_t tail_votes = 0;                     // voters in the last chunk, whose bytes are already stored
+        tail = process_set(hits, acc, vote, begin, p, s, tail_base, tail_mask, tail_fI, tail_wt, tail_votes, c, calls, true) & 1u;
+        if ((tail_votes >> lane) & 1ull) vote[tail_base + lane] = 1;
     }
-    if (!EMIT && lane == 0) { call_cnt[c] = s.ncalls; tail_ev[c] = (uint8_t)tail; }
+    if (lane == 0) { call_cnt[c] = s.ncalls; tail_ev[c] = (uint8_t)tail; }
     }
+}
+
+// staged CALL records -> calls[] in emission order: container c's records sit at staged[chs[c] / minHits ...] and go to
+// calls[call_off[c] ...].  W lanes per container (W = 64: few containers with many CALLs; W = 1: millions of reads).
+template <int W>
+__global__ __launch_bounds__(256) void compact_calls_kernel(const kg_call *__restrict__ staged, const int64_t *__restrict__ chs,
+                                                            const uint32_t *__restrict__ call_cnt, const uint32_t *__restrict__ call_off,
+                                                            uint32_t n_cont, uint32_t min_hits, kg_call *__restrict__ calls)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t c = t / W;
+    if (c >= n_cont) return;
+    const uint32_t n = call_cnt[c];
+    const kg_call *src = staged + (uint32_t)chs[c] / min_hits;
+    kg_call *dst = calls + call_off[c];
+    for (uint32_t k = (uint32_t)(t % W); k < n; k += W) dst[k] = src[k];
 }
 
 // ccs[c] = call_off[c] widened, plus sentinel
@@ -311,14 +340,15 @@ __global__ void call_starts_kernel(const uint32_t *call_off, uint64_t n_cont, co
     ccs[c] = c == n_cont ? (int64_t)*total : (int64_t)call_off[c];
 }
 
-// OTU vote (KGJ:413-439), one wave per sequence: replay the voters of every CALL of the sequence in
-// emission order against the 5-entry buffer that persists across the sequence's containers
-// (KGJ:528, 540).  The buffer lives in wave-uniform registers; the voters of one chunk are visited
-// in ascending lane order.
-__global__ __launch_bounds__(256) void otu_wave_kernel(const kg_hit *__restrict__ hits, const uint8_t *__restrict__ acc,
-                                                       const kg_call *__restrict__ calls, const CallSpan *__restrict__ spans,
-                                                       const int64_t *__restrict__ ccs, uint32_t n_seqs, uint32_t per,
-                                                       kg_otu *otu, uint32_t per_wave, const kg_otu *__restrict__ otu_init)
+// OTU vote (KGJ:413-439), one wave per sequence: the records whose vote counted towards a CALL (vote[], left by
+// calls_wave_kernel) are replayed in record order -- the reference's order: CALLs of a container are emitted with
+// ascending, disjoint voter ranges, containers in order -- against the 5-entry buffer that persists across the
+// sequence's containers (KGJ:528, 540).  The buffer lives in wave-uniform registers; the records are streamed in
+// 64-record chunks, the next chunk requested before the current one is replayed.
+__global__ __launch_bounds__(256) void otu_wave_kernel(const kg_hit *__restrict__ hits, const uint8_t *__restrict__ vote,
+                                                       const int64_t *__restrict__ chs, const uint32_t *__restrict__ call_cnt,
+                                                       uint32_t n_seqs, uint32_t per, kg_otu *otu, uint32_t per_wave,
+                                                       const kg_otu *__restrict__ otu_init)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t s_first = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6))) * per_wave;
@@ -331,45 +361,48 @@ __global__ __launch_bounds__(256) void otu_wave_kernel(const kg_hit *__restrict_
 #pragma unroll
         for (int k = 0; k < KG_OI_BUFSZ; k++) { cnt[k] = r0.count[k]; oi[k] = r0.oI[k]; }
     }
-    const int64_t c0 = ccs[(uint64_t)s * per], c1 = ccs[(uint64_t)(s + 1) * per];
-    for (int64_t c = c0; c < c1; c++) {
-        const int32_t fI = calls[c].fI;
-        const CallSpan sp = spans[c];
-        for (uint32_t b = sp.lo; b <= sp.last_hit; b += 64) {
-            const uint32_t i = b + lane;
-            bool vote = false;
-            int32_t o = 0;
-            if (i <= sp.last_hit) { vote = (acc[i] & KG_EV_ACCEPTED) != 0 && hits[i].fI == fI; o = hits[i].oI; }
-            uint64_t m = __ballot(vote);
-            while (m) {
-                const int k = __builtin_ctzll(m);
-                m &= m - 1;
-                const int32_t ok = rl(o, k);
-                int j = n;                                              // KGJ:416-417 linear search
+    for (uint32_t f = 0; f < per; f++) {
+    const uint64_t c = (uint64_t)s * per + f;
+    if (call_cnt[c] == 0) continue;                                     // no CALL, no voters (metagenome contigs: almost all)
+    const uint32_t begin = (uint32_t)chs[c], end = (uint32_t)chs[c + 1];
+    bool n_vote = false;
+    int32_t n_o = 0;
+    if (begin + (uint32_t)lane < end) { n_vote = vote[begin + lane] != 0; n_o = hits[begin + lane].oI; }
+    for (uint32_t b = begin; b < end; b += 64) {
+        const bool v = n_vote;
+        const int32_t o = n_o;
+        n_vote = false; n_o = 0;
+        if (b + 64u + (uint32_t)lane < end) { n_vote = vote[b + 64u + lane] != 0; n_o = hits[b + 64u + lane].oI; }
+        uint64_t m = __ballot(v);
+        while (m) {
+            const int k = __builtin_ctzll(m);
+            m &= m - 1;
+            const int32_t ok = rl(o, k);
+            int j = n;                                              // KGJ:416-417 linear search
 #pragma unroll
-                for (int t = KG_OI_BUFSZ - 1; t >= 0; t--)
-                    if (t < n && oi[t] == ok) j = t;
-                if (j == n) {                                           // KGJ:418-427
-                    if (n == KG_OI_BUFSZ) j--; else n++;
+            for (int t = KG_OI_BUFSZ - 1; t >= 0; t--)
+                if (t < n && oi[t] == ok) j = t;
+            if (j == n) {                                           // KGJ:418-427
+                if (n == KG_OI_BUFSZ) j--; else n++;
 #pragma unroll
-                    for (int t = 0; t < KG_OI_BUFSZ; t++)
-                        if (t == j) { oi[t] = ok; cnt[t] = 1; }
-                } else {
+                for (int t = 0; t < KG_OI_BUFSZ; t++)
+                    if (t == j) { oi[t] = ok; cnt[t] = 1; }
+            } else {
 #pragma unroll
-                    for (int t = 0; t < KG_OI_BUFSZ; t++)
-                        if (t == j) cnt[t]++;
-                }
+                for (int t = 0; t < KG_OI_BUFSZ; t++)
+                    if (t == j) cnt[t]++;
+            }
 #pragma unroll
-                for (int t = KG_OI_BUFSZ - 1; t >= 1; t--) {            // KGJ:432-437 bubble toward the front
-                    if (j == t && cnt[t - 1] <= cnt[t]) {
-                        int32_t tc = cnt[t - 1], to = oi[t - 1];
-                        cnt[t - 1] = cnt[t]; oi[t - 1] = oi[t];
-                        cnt[t] = tc; oi[t] = to;
-                        j = t - 1;
-                    }
+            for (int t = KG_OI_BUFSZ - 1; t >= 1; t--) {            // KGJ:432-437 bubble toward the front
+                if (j == t && cnt[t - 1] <= cnt[t]) {
+                    int32_t tc = cnt[t - 1], to = oi[t - 1];
+                    cnt[t - 1] = cnt[t]; oi[t - 1] = oi[t];
+                    cnt[t] = tc; oi[t] = to;
+                    j = t - 1;
                 }
             }
         }
+    }
     }
     if (lane == 0) {
         kg_otu r;

@@ -595,40 +595,49 @@ int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc
         kg::AggParams ap;
         ap.min_hits = p->min_hits; ap.min_weighted_hits = p->min_weighted_hits;
         ap.max_gap = p->max_gap; ap.order_constraint = p->order_constraint ? 1 : 0;
-        uint32_t *d_ccnt = nullptr, *d_coff = nullptr; kg::CallSpan *d_spans = nullptr;
+        uint32_t *d_ccnt = nullptr, *d_coff = nullptr;
+        kg_call *d_staged = nullptr;
+        uint8_t *d_vote = nullptr;
         if ((rc = dalloc(t, (void **)&res->d_ev, n_hits))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_tail_ev, n_cont))) return rc;
         uint8_t *d_acc = res->d_ev;
         if ((rc = sc.get(&d_ccnt, n_cont))) return rc;
         if ((rc = sc.get(&d_coff, n_cont))) return rc;
+        if ((rc = sc.get(&d_vote, n_hits))) return rc;
+        // a hit votes for at most one CALL and a CALL needs >= minHits voters: container c's CALLs fit in
+        // [chs[c] / minHits, chs[c + 1] / minHits) of the staging array (kg_aggregate.hpp)
+        if ((rc = sc.get(&d_staged, (size_t)(n_hits / (uint64_t)p->min_hits + 1)))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_ccs, (n_cont + 1) * 8))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_otu, (size_t)(n_seqs ? n_seqs : 1) * sizeof(kg_otu)))) return rc;
         // one wave per container; several consecutive containers per wave when there are millions of them (short reads)
         const uint32_t cpw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, n_cont / (1u << 17)));
         uint32_t cgrid = (uint32_t)(((n_cont + cpw - 1) / cpw + 3) / 4);
         if (n_cont) {
-            hipLaunchKernelGGL((kg::calls_wave_kernel<false>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
-                               (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, (const uint32_t *)nullptr, (kg_call *)nullptr,
-                               (kg::CallSpan *)nullptr, cpw);
+            hipLaunchKernelGGL(kg::calls_wave_kernel, dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
+                               (uint32_t)n_cont, ap, d_acc, d_vote, res->d_tail_ev, d_ccnt, d_staged, cpw);
             HIP_TRY(hipGetLastError());
         }
         if ((rc = prefix_sum(t, d_ccnt, n_cont, d_coff, d_partial, d_totals + 4))) return rc;
         uint64_t h_calls = 0;
         HIP_TRY(hipMemcpyAsync(&h_calls, d_totals + 4, 8, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        n_calls = n_cont ? h_calls : 0;
-        if ((rc = dalloc(t, (void **)&res->d_calls, n_calls * sizeof(kg_call)))) return rc;
-        if ((rc = sc.get(&d_spans, n_calls))) return rc;
-        if (n_cont && n_calls) {
-            hipLaunchKernelGGL((kg::calls_wave_kernel<true>), dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
-                               (uint32_t)n_cont, ap, d_acc, res->d_tail_ev, d_ccnt, d_coff, res->d_calls, d_spans, cpw);
-        }
-        hipLaunchKernelGGL(kg::call_starts_kernel, dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream, d_coff,
-                           n_cont, d_totals + 4, res->d_ccs);
+        // the OTU votes need the voter marks only: they run while the host waits for the CALL total
         if (n_seqs) {
             const uint32_t spw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (uint64_t)n_seqs / (1u << 17)));
             hipLaunchKernelGGL(kg::otu_wave_kernel, dim3((uint32_t)((((uint64_t)n_seqs + spw - 1) / spw + 3) / 4)), dim3(256), 0, t->stream,
-                               res->d_hits, d_acc, res->d_calls, d_spans, res->d_ccs, (uint32_t)n_seqs, PER, res->d_otu, spw, d_otu_init);
+                               res->d_hits, d_vote, res->d_chs, d_ccnt, (uint32_t)n_seqs, PER, res->d_otu, spw, d_otu_init);
+        }
+        hipLaunchKernelGGL(kg::call_starts_kernel, dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream, d_coff,
+                           n_cont, d_totals + 4, res->d_ccs);
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        n_calls = n_cont ? h_calls : 0;
+        if ((rc = dalloc(t, (void **)&res->d_calls, n_calls * sizeof(kg_call)))) return rc;
+        if (n_cont && n_calls) {
+            if (n_cont < (1u << 17))
+                hipLaunchKernelGGL((kg::compact_calls_kernel<64>), dim3((uint32_t)((n_cont * 64 + 255) / 256)), dim3(256), 0, t->stream,
+                                   d_staged, res->d_chs, d_ccnt, d_coff, (uint32_t)n_cont, (uint32_t)p->min_hits, res->d_calls);
+            else
+                hipLaunchKernelGGL((kg::compact_calls_kernel<1>), dim3((uint32_t)((n_cont + 255) / 256)), dim3(256), 0, t->stream,
+                                   d_staged, res->d_chs, d_ccnt, d_coff, (uint32_t)n_cont, (uint32_t)p->min_hits, res->d_calls);
         }
         HIP_TRY(hipGetLastError());
     }
