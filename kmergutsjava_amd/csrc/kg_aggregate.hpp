@@ -56,10 +56,16 @@ __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_read
 // range); its voters are marked in vote[] -- those of the caller's chunk in cur_votes, which the caller stores with the
 // chunk's other bytes.
 // returns bit 0: a CALL was made, bit 1: the last two members were kept
+struct ChunkRegs {               // one 64-record chunk held in registers: base and membership bits wave-uniform, the rest per lane
+    uint32_t base;
+    uint64_t mask;
+    int32_t fI, pos;
+    float wt;
+};
+
 __device__ __forceinline__ uint32_t process_set(const kg_hit *__restrict__ h, const uint8_t *__restrict__ acc, uint8_t *__restrict__ vote,
-                                            uint32_t begin, const AggParams &p, AggState &s, uint32_t cur_base, uint64_t cur_mask,
-                                            int32_t cur_fI, float cur_wt, uint64_t &cur_votes, uint32_t container, kg_call *calls,
-                                            bool allow_carry)
+                                            uint32_t begin, const AggParams &p, AggState &s, const ChunkRegs &cur, const ChunkRegs &prv,
+                                            uint64_t &cur_votes, uint32_t container, kg_call *calls, bool allow_carry)
 {
     const int lane = threadIdx.x & 63;
     int32_t fICount = 0;
@@ -72,10 +78,14 @@ __device__ __forceinline__ uint32_t process_set(const kg_hit *__restrict__ h, co
         int32_t fI = 0;
         float wt = 0.f;
         bool mem = false;
-        if (b == cur_base) {                 // the caller's chunk: its records are in registers (dense inputs: most sets)
-            fI = cur_fI;
-            wt = cur_wt;
-            mem = in && ((cur_mask >> lane) & 1ull) != 0;
+        if (b == cur.base) {                 // the caller's chunk and the one before it are in registers: a set rarely
+            fI = cur.fI;                     // reaches further back (runs between gaps: ~40 records in sparse inputs,
+            wt = cur.wt;                     // ~13 in dense ones), so most sets are processed without a memory round trip
+            mem = in && ((cur.mask >> lane) & 1ull) != 0;
+        } else if (b == prv.base) {
+            fI = prv.fI;
+            wt = prv.wt;
+            mem = in && ((prv.mask >> lane) & 1ull) != 0;
         } else if (in) {
             fI = h[i].fI;
             wt = h[i].functionWt;
@@ -96,11 +106,18 @@ __device__ __forceinline__ uint32_t process_set(const kg_hit *__restrict__ h, co
     uint32_t what = 0;
     if (fICount >= p.min_hits && weighted >= (float)p.min_weighted_hits) {      // KGJ:397
         what = 1;
+        // positions of the set's first record and of the last voter: out of the register chunks when they are there
+        auto pos_of = [&](uint32_t i) -> int32_t {
+            if (i - cur.base < 64u) return rl(cur.pos, (int)(i - cur.base));
+            if (i - prv.base < 64u) return rl(prv.pos, (int)(i - prv.base));
+            return h[i].from0InProt;
+        };
+        const int32_t pos_lo = pos_of(s.lo), pos_last = pos_of(lastHit);
         if (lane == 0) {
             kg_call c;
             c.container = container;
-            c.start = h[s.lo].from0InProt;                              // KGJ:399: first record of the set, any fI
-            c.end = h[lastHit].from0InProt + (KG_K - 1);                // KGJ:400
+            c.start = pos_lo;                                           // KGJ:399: first record of the set, any fI
+            c.end = pos_last + (KG_K - 1);                              // KGJ:400
             c.count = fICount; c.fI = s.currentFI; c.weightedHits = weighted;
             calls[s.ncalls] = c;
         }
@@ -109,8 +126,10 @@ __device__ __forceinline__ uint32_t process_set(const kg_hit *__restrict__ h, co
         for (uint32_t b = c0; b <= s.last; b += 64) {
             const uint32_t i = b + lane;
             const bool in = i >= s.lo && i <= s.last;
-            if (b == cur_base) {
-                cur_votes |= __ballot(in && ((cur_mask >> lane) & 1ull) != 0 && cur_fI == s.currentFI);
+            if (b == cur.base) {
+                cur_votes |= __ballot(in && ((cur.mask >> lane) & 1ull) != 0 && cur.fI == s.currentFI);
+            } else if (b == prv.base) {
+                if (in && ((prv.mask >> lane) & 1ull) != 0 && prv.fI == s.currentFI) vote[i] = 1;
             } else if (in && (acc[i] & KG_EV_ACCEPTED) != 0 && h[i].fI == s.currentFI) {
                 vote[i] = 1;
             }
@@ -178,10 +197,9 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
     s.last_pos = s.last_fI = s.last_avg = s.prev_fI = 0;
     s.cnt = 0; s.currentFI = 0; s.ncalls = 0;
     int32_t carry_pos = 0, carry_fI = 0;            // fields of the record before this chunk
-    uint32_t tail_base = 0xFFFFFFFFu;               // last chunk, its membership bits and records, for the final flush
-    uint64_t tail_mask = 0;
-    int32_t tail_fI = 0;
-    float tail_wt = 0.f;
+    ChunkRegs pv, ppv;                              // the chunk before the current one and the one before that (registers)
+    // "no such chunk": a base no record index comes within 64 of (kg_scan takes < 2^32 - 256 hit records)
+    pv.base = ppv.base = 0xFFFFFF00u; pv.mask = ppv.mask = 0; pv.fI = ppv.fI = pv.pos = ppv.pos = 0; pv.wt = ppv.wt = 0.f;
 
     for (uint32_t base = begin; base < end; base += 64) {
         const int n = (int)min(64u, end - base);
@@ -192,6 +210,8 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
         uint64_t accmask;
         uint64_t votes = 0;                          // records of this chunk whose vote counted towards a CALL
         EvMasks em = {0, 0, 0, 0, 0, 0};
+        ChunkRegs cu;                                // (cu.mask follows accmask at every call)
+        cu.base = base; cu.mask = 0; cu.fI = fI; cu.pos = pos; cu.wt = wt;
 
         // the fast path needs every record of the chunk to be accepted and the list's last member to be
         // the record just before the chunk (after a cap overflow the list can end far behind)
@@ -231,7 +251,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                         s.last = ik - 1;
                         // no carry is possible here: a pair of equal, non-current fI at the end of the list
                         // would have fired the pair rule when its second record was appended
-                        what = process_set(hits, acc, vote, begin, p, s, base, accmask, fI, wt, votes, c, calls, false);
+                        what = (cu.mask = accmask, process_set(hits, acc, vote, begin, p, s, cu, pv, votes, c, calls, false));
                     } else {
                         s.cnt = 0;
                     }
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                 s.cnt++;                                                                 // KGJ:496-497
                 if (s.cnt > 1 && s.currentFI != fk && ((eqm >> k) & 1)) {                // KGJ:503-508
                     s.last = ik; s.prev = ik - 1; s.last_fI = fk; s.prev_fI = fk;
-                    em.after(k, process_set(hits, acc, vote, begin, p, s, base, accmask, fI, wt, votes, c, calls, true));
+                    em.after(k, (cu.mask = accmask, process_set(hits, acc, vote, begin, p, s, cu, pv, votes, c, calls, true)));
                 }
                 k0 = k + 1;
             }
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                 if (s.cnt > 0 && (int32_t)((uint32_t)s.last_pos + (uint32_t)p.max_gap) < pk) {      // KGJ:477-484
                     uint32_t what = 0;
                     if (s.cnt >= p.min_hits)
-                        what = process_set(hits, acc, vote, begin, p, s, base, accmask, fI, wt, votes, c, calls, true);
+                        what = (cu.mask = accmask, process_set(hits, acc, vote, begin, p, s, cu, pv, votes, c, calls, true));
                     else
                         s.cnt = 0;
                     em.before(k, what);
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                         accmask |= 1ull << k;
                     }
                     if (s.cnt > 1 && s.currentFI != fk && s.prev_fI == s.last_fI)                    // KGJ:503-508
-                        em.after(k, process_set(hits, acc, vote, begin, p, s, base, accmask, fI, wt, votes, c, calls, true));
+                        em.after(k, (cu.mask = accmask, process_set(hits, acc, vote, begin, p, s, cu, pv, votes, c, calls, true)));
                 }
             }
         }
@@ -301,16 +321,15 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
         }
         carry_pos = rl(pos, n - 1);
         carry_fI = rl(fI, n - 1);
-        tail_base = base;
-        tail_mask = accmask;
-        tail_fI = fI;
-        tail_wt = wt;
+        ppv = pv;
+        cu.mask = accmask;
+        pv = cu;
     }
     uint32_t tail = 0;
     if (s.cnt >= p.min_hits) {                                                                       // KGJ:511-513
         uint64_t tail_votes = 0;                     // voters in the last chunk, whose bytes are already stored
-        tail = process_set(hits, acc, vote, begin, p, s, tail_base, tail_mask, tail_fI, tail_wt, tail_votes, c, calls, true) & 1u;
-        if ((tail_votes >> lane) & 1ull) vote[tail_base + lane] = 1;
+        tail = process_set(hits, acc, vote, begin, p, s, pv, ppv, tail_votes, c, calls, true) & 1u;
+        if ((tail_votes >> lane) & 1ull) vote[pv.base + lane] = 1;
     }
     if (lane == 0) { call_cnt[c] = s.ncalls; tail_ev[c] = (uint8_t)tail; }
     }

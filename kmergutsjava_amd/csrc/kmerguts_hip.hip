@@ -251,7 +251,6 @@ int table_finish(kg_table *t)
     HIP_TRY(hipStreamSynchronize(t->stream));
     HIP_TRY(hipFree(d_occ));
     t->occupied = occ;
-    for (auto &e : t->ev) HIP_TRY(hipEventCreate(&e));
     for (auto &e : t->pev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&t->stream3, hipStreamNonBlocking));
@@ -269,7 +268,9 @@ int table_new(int device, kg_table **out)
     if (!t) return fail(KG_ERR_NOMEM, "out of host memory");
     t->device = device;
     hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete t; return fail(KG_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    for (auto &ev : t->ev)
+        if (e == hipSuccess) e = hipEventCreate(&ev);               // (a table-less context of kg_aggregate_hits uses them too)
+    if (e != hipSuccess) { kg_table_close(t); return fail(KG_ERR_DEVICE, std::string("hipStreamCreate / hipEventCreate: ") + hipGetErrorString(e)); }
     *out = t;
     return KG_OK;
 }

@@ -62,6 +62,22 @@ def test_gather_hits_and_process_aa_seq(debug):
 
 
 @pytest.mark.gpu
+def test_aggregate_hits_result_views():
+    """kg_aggregate_hits hands out an ordinary result: host views, device views and kg_result_copy_hits work on it."""
+    from kmergutsjava_amd import hotpath, _native as N
+    rng = np.random.default_rng(3)
+    tup = sorted(_random_hits(rng, 300), key=lambda t: t[1])
+    rec = np.zeros(len(tup), dtype=N.HIT_DTYPE)
+    for i, (o, pos, avg, fi, wt) in enumerate(tup):
+        rec[i] = (0, pos, o, avg, fi, wt)
+    with hotpath.aggregate_hits(rec, [0, len(rec)], 1, hotpath.Params(aa=True, min_hits=2)) as r:
+        assert r.stats["n_hits"] == len(rec) and r.stats["n_calls"] == len(r.calls()) > 0
+        assert r.hits().tobytes() == rec.tobytes() == r.copy_hits().tobytes()
+        assert r.device_view("hits").cpu().numpy().tobytes() == rec.tobytes()
+        assert int(r.container_call_start()[-1]) == r.stats["n_calls"] and len(r.hit_events()) == len(rec)
+
+
+@pytest.mark.gpu
 def test_process_set_of_hits():
     from kmergutsjava_amd import KmerGutsJava as K
     fn = ["function %d" % i for i in range(8)]
