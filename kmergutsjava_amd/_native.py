@@ -73,6 +73,16 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # libkmerguts_hip.so is linked against the system's libamdhip64; PyTorch ships a copy of its own under the same
+    # SONAME.  Whichever is loaded first serves both, and torch.cuda only comes up on its own copy (measured on the GPU
+    # box: library first, torch second -> torch.cuda.is_available() is False).  The package uses torch for device
+    # tensors and torch.distributed, so torch's runtime goes first; KG_NO_TORCH_PRELOAD=1 skips the ~1.5 s import for
+    # processes that never touch torch.cuda.
+    if not os.environ.get("KG_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "%s is missing: build it with `python -m kmergutsjava_amd.build` "

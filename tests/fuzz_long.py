@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Long differential fuzz against the CPU oracle (test infrastructure; not collected by pytest):
+    python tests/fuzz_long.py [n_workloads=400] [first_seed=1000]
+Every workload of tests/fuzz_workloads.py through both scan strategies, records, event bytes, counters and flags compared
+with the oracle.  Prints one JSON summary line; exit code 1 on the first difference."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fuzz_workloads import workloads          # noqa: E402
+from helpers import assert_same_records       # noqa: E402
+
+KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_SLACK", "KG_TEST_TINY_LISTS", "KG_PART_OVF_GROUPS")
+
+
+def main():
+    from kmergutsjava_amd import hotpath
+    from oracle import kgo
+    kgo.build()
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    done = n_part = calls = hits = 0
+    for seed in range(seed0, seed0 + (n + 24) // 25):
+        for w in workloads(25, seed):
+            p = w["params"]
+            ora = kgo.run(w["img"], w["raw"], w["off"], lookup_mode=1, **p)
+            with hotpath.SignatureTable.from_bytes(w["img"]) as tab:
+                for mode in ("0", "1"):
+                    for k in KNOBS:
+                        os.environ.pop(k, None)
+                    os.environ["KG_PARTITION"] = mode
+                    if mode == "1":
+                        os.environ.update(w["env"])
+                    with tab.scan(w["raw"], w["off"], hotpath.Params(counters=True, **p)) as r:
+                        assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s" % (seed, w["it"], mode, w["env"]))
+                        assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
+                        n_part += r.stats["partitioned"]
+            done += 1
+            calls += len(ora["calls"])
+            hits += len(ora["hits"])
+            if done >= n:
+                break
+    print(json.dumps({"workloads": done, "scans": 2 * done, "ran_partitioned": n_part, "oracle_hits": hits, "oracle_calls": calls,
+                      "all_identical": True}))
+
+
+if __name__ == "__main__":
+    main()
