@@ -13,10 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkmerguts_hip.so")
-# the atomic optimizer turns a one-lane atomicAdd on a uniform address into mbcnt + atomic + readfirstlane, i.e. a wait for
-# the result right behind the atomic: the tag pass draws its tickets ahead of their use (kg_partition.hpp)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+               "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

@@ -653,167 +653,6 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
     }
 }
 
-// The same pass as a software pipeline, one independent walk per WAVE.
-//
-// Measured on the kernel above (profiles/r02_pipeline.md, ablation): its time is the SUM of the entry latency (a stream
-// from HBM), the tag latency (L2) and 3.7 ms of VALU work per Gbp, not their maximum -- beside a scatter workgroup only
-// two tag waves fit a SIMD's registers, too few to hide a chain of two dependent loads, a workgroup barrier and an
-// atomic per hand-out.  Here
-//   * the waves of XCD group x draw tickets from ONE counter per group; ticket g is a quarter (every fourth batch) of
-//     region (g / 4) % n_regions of the group's bucket g / 4 / n_regions, so the group works through its buckets in
-//     order without a hand-over and without a barrier, and its 512 waves are within 128 regions = half a bucket of
-//     each other: one bucket's tags in the L2, two at a boundary, as before (whole regions per wave: 13.5 ms -- the
-//     waves spread over two to three buckets and the tags no longer fit the L2);
-//   * a wave always holds a drawn ticket, a resolved next region (its fill read by a scalar load) and the entries of
-//     its next two batches: batch i + 2 is requested before the tags of batch i are waited for.
-// Every load in the loop is unconditional (clamped address, result discarded by a select) and in a fixed order: a load
-// under a branch makes the compiler's s_waitcnt bookkeeping give up (vmcnt(0) in front of the tag compare = the
-// prefetch is waited for too).  Distance two, not one: the candidate stores of a batch are conditional, so only loads
-// issued BEFORE them can be waited for without also waiting for everything younger.  The ISA is checked for this
-// (tools/check_tag_isa.py): four tag loads, four entry loads, then s_waitcnt vmcnt(7) .. vmcnt(4), no v_mov of an
-// entry register pair at the loop end.
-struct TagBatch { uint32_t b, w, c0, n; };
-constexpr uint32_t kTagParts = 4;            // a region is walked by four tickets: part p = its batches p, p + 4, ...
-constexpr uint32_t kTicketStride = 32;       // words between the ticket counters of two XCD groups (one 128-byte line each)
-
-template <bool COUNTERS>
-__global__ __launch_bounds__(256) void bucket_tag_pipe_kernel(
-    const uint8_t *tags, uint64_t limit, uint64_t num_sigs, const uint64_t *ent /* no __restrict__: see step() */,
-    const uint32_t *__restrict__ fill, uint32_t n_regions, uint32_t cap, uint32_t n_buckets, uint32_t shift,
-    uint32_t *tickets /* [8 * kTicketStride], zeroed */,
-    CandRec *cand, uint32_t *__restrict__ cand_used, unsigned long long *cand_cursor, uint64_t cand_cap,
-    unsigned long long *ctr)
-{
-    constexpr int N = kProbeN;
-    constexpr uint32_t kBatch = 64u * N;
-    const int lane = threadIdx.x & 63;
-    unsigned long long ctr_slots = 0;
-    bool ran_off = false;
-    UListState u;
-    u.base = 0; u.used = kUChunk; u.have = false;      // "full": the first append takes a chunk
-
-    const uint32_t x = blockIdx.x & 7u;
-    uint32_t *const ticket = tickets + x * kTicketStride;
-    const uint32_t group_buckets = x < n_buckets ? (n_buckets - x + 7u) / 8u : 0u;
-    const uint32_t n_tickets = group_buckets * n_regions * kTagParts;
-    auto fill_of = [&](uint32_t bb, uint32_t ww) -> uint32_t {
-        return bb < n_buckets ? min(fill[(uint64_t)bb * n_regions + ww], cap) : 0u;     // (bulk appends may have run past the region)
-    };
-    // the walk: d0 = the batch being probed, d1 / d2 = the two behind it (entries requested); (nb, nw) filled to nn =
-    // the region behind d2's; drawn = the ticket behind that (lane 0, possibly still in flight)
-    uint32_t nb = n_buckets, nw = 0, nn = 0, np = 0;
-    uint32_t drawn = 0;
-    auto draw = [&]() { if (lane == 0) drawn = atomicAdd(ticket, 1u); };
-    auto next_region = [&]() -> TagBatch {
-        const TagBatch d = {nb, nw, np * kBatch, nn};
-        const uint32_t g = min((uint32_t)__builtin_amdgcn_readfirstlane(drawn), n_tickets);
-        const uint32_t r = g / kTagParts;
-        np = g % kTagParts;
-        const uint32_t j = r / n_regions;
-        nw = r - j * n_regions;
-        nb = g < n_tickets ? x + 8u * j : n_buckets;
-        nn = fill_of(nb, nw);
-        draw();
-        return d;
-    };
-    auto batch_after = [&](const TagBatch &d) -> TagBatch {
-        if (d.c0 + kTagParts * kBatch < d.n) return TagBatch{d.b, d.w, d.c0 + kTagParts * kBatch, d.n};
-        return next_region();
-    };
-    auto request = [&](uint64_t (&e)[N], const TagBatch &d) {
-        const uint32_t bb = d.b < n_buckets ? d.b : 0u;                       // (past the end: n == 0, any mapped address)
-        const uint64_t *src = ent + ((uint64_t)bb * n_regions + d.w) * cap;
-        const uint32_t last = d.n ? d.n - 1u : 0u;
-#pragma unroll
-        for (int k = 0; k < N; k++) e[k] = __builtin_nontemporal_load(src + min(d.c0 + (uint32_t)k * 64u + (uint32_t)lane, last));
-    };
-    draw();
-    (void)next_region();                               // primes (nb, nw, nn) with the first ticket
-    TagBatch d0 = next_region();
-    TagBatch d1 = batch_after(d0);
-    TagBatch d2 = batch_after(d1);
-    uint64_t evA[N], evB[N];
-    request(evA, d0);
-    asm volatile("" ::: "memory");                     // in this order: the loop's first wait is for evA with evB still in flight
-    request(evB, d1);
-
-    // one batch: e holds d0's entries on entry and d2's (in flight) on exit
-    auto step = [&](uint64_t (&e)[N]) {
-        uint64_t home[N], cur[N];
-        uint32_t id[N], quo[N], fp[N], skip[N];
-        bool valid[N];
-        Tags16 tg[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) {
-            const uint64_t ek = e[k];
-            valid[k] = (d0.c0 + (uint32_t)k * 64u + (uint32_t)lane < d0.n) & (ek != kEntInvalid);
-            // copies, not the registers of e[k] themselves: e[k] must be dead before request() reloads it, or the
-            // compiler loads into fresh registers and moves them at the loop end -- behind a wait for every load in flight
-            uint32_t low;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(low) : "v"((uint32_t)ek));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(id[k]) : "v"((uint32_t)(ek >> 32)));
-            home[k] = ((uint64_t)d0.b << shift) | (low & ((1u << shift) - 1u));
-            quo[k] = low >> shift;
-            fp[k] = tag_qs(quo[k], home[k]);
-            cur[k] = probe_window(home[k], &skip[k]);
-            tg[k] = load_tags(tags + (valid[k] ? cur[k] : 0ull));
-        }
-        asm volatile("" ::: "memory");                 // (instruction selection otherwise puts a tag load below the entry loads)
-        request(e, d2);                                // behind the tag loads: loads complete in order
-        asm volatile("" ::: "memory");
-        // branch-free: a load whose only use sits under a branch is sunk into it by the compiler (and is then a
-        // conditional load again)
-        uint32_t candm = 0, walkm = 0;
-#pragma unroll
-        for (int k = 0; k < N; k++) {
-            bool emp;
-            const int i = first_stop(tg[k], fp[k], &emp, skip[k]);
-            cur[k] += (uint64_t)i;
-            const bool walk = valid[k] & (i == 16);
-            const bool miss = valid[k] & (i != 16) & emp;
-            const bool match = valid[k] & (i != 16) & !emp;
-            candm |= (uint32_t)(walk | match) << k;
-            walkm |= (uint32_t)walk << k;
-            ran_off |= miss & (cur[k] >= limit);               // the "empty slot" is the padding behind the last record
-            if (COUNTERS) ctr_slots += miss ? (cur[k] < limit ? cur[k] + 1 : limit) - home[k] : 0ull;
-        }
-        uint32_t cnt[N], rank[N], total = 0;
-#pragma unroll
-        for (int k = 0; k < N; k++) {
-            const unsigned long long m = __ballot((candm >> k) & 1u);
-            cnt[k] = (uint32_t)__popcll(m);
-            rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            total += cnt[k];
-        }
-        if (total) {
-            unsigned long long at = chunk_reserve(u, total, cand_used, cand_cursor, cand_cap, lane);
-            if (at != ~0ull) {
-#pragma unroll
-                for (int k = 0; k < N; k++) {
-                    if ((candm >> k) & 1u) {
-                        CandRec c;
-                        c.val = (uint64_t)quo[k] * num_sigs + home[k];          // the k-mer value, candidates only
-                        c.id = id[k]; c.walked = (uint32_t)(cur[k] - home[k]) | (((walkm >> k) & 1u) ? kWalkOn : 0u);
-                        cand[at + rank[k]] = c;
-                    }
-                    at += cnt[k];
-                }
-            }
-        }
-        d0 = d1; d1 = d2; d2 = batch_after(d2);
-    };
-    while (d0.b < n_buckets) {
-        step(evA);
-        step(evB);                                     // (past the end: an empty batch)
-    }
-    chunk_finish(u, cand_used, cand_cap, lane);
-    flush_ran_off(ran_off, ctr, lane);
-    if (COUNTERS) {
-        for (int off = 32; off > 0; off >>= 1) ctr_slots += __shfl_down(ctr_slots, off);
-        if (lane == 0) atomicAdd(&ctr[1], ctr_slots);
-    }
-}
-
 // Verify pass: one wave per candidate chunk at a time, one lane per candidate.
 template <bool AA, bool COUNTERS>
 __global__ __launch_bounds__(256) void verify_kernel(

@@ -817,7 +817,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if ((rc = sc.get(&d_fill, (size_t)n_regions_total * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_ovf_ent, (size_t)ovf_cap * kg::kGroup * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_ovf_bucket, (size_t)ovf_cap * n_chunks_p))) return rc;
-        const size_t next_stride = std::max<size_t>((size_t)part_buckets + 8, 8 * kg::kTicketStride);   // hand-out counters / tickets
+        const size_t next_stride = (size_t)part_buckets + 8;
         if ((rc = sc.get(&d_next, next_stride * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_ovfc, 8 * kMaxChunks))) return rc;       // per chunk: [0] overflow groups, [1] low-complexity blocks
         uint32_t *d_lowc = nullptr;                                    // block numbers set aside by the scatter pass
@@ -838,7 +838,6 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         // workgroups (profiles/r02_pipeline.md: 20.8 -> 20.4 ms per Gbp)
         const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 4u) & ~7u;
         const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
-        const bool tag_pipe = env_u32("KG_TAG_PIPE", 0u) != 0;
         // per-chunk lists: hits (unordered) and candidates = fingerprint matches (hits + ~0.4 % of the probes) + the
         // ~2 % of the probes whose first tag window decides nothing
         const uint64_t list_slack = (uint64_t)(std::max(probe_grid, verify_grid) + 64) * 4 * kg::kUChunk + 4096;
@@ -903,14 +902,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
 #define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
                     candused_c, ccur_c, ccap, d_ctr
 #define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_masks, d_ctr
-#define KG_TAGP_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, next_c, cand_c, candused_c, \
-                     ccur_c, ccap, d_ctr
-                if (tag_pipe) {
-                    if (counters) hipLaunchKernelGGL((kg::bucket_tag_pipe_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAGP_ARGS);
-                    else hipLaunchKernelGGL((kg::bucket_tag_pipe_kernel<false>), dim3(probe_grid), dim3(256), 0, s2, KG_TAGP_ARGS);
-                } else if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
+                if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
                 else hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
-#undef KG_TAGP_ARGS
                 HIP_TRY(hipEventRecord(t->pev[2 * c + 1], s2));
                 HIP_TRY(hipStreamWaitEvent(s3, t->pev[2 * c + 1], 0));
                 if (counters) {

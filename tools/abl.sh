@@ -1,5 +1,11 @@
 #!/bin/bash
-# tag-pass ablation (tuning aid): per-variant kernel durations, passes serialised (1 chunk) and pipelined (4 chunks)
+# tag-pass ablation (tuning aid): per-variant kernel durations, passes serialised (1 chunk) and pipelined (4 chunks).
+# Variant libraries first, here (they travel with the snapshot):
+#   git apply tools/tag_ablate.patch
+#   for k in 1 3 5 9 13; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DKG_ABL=$k -o tools/abl/libkg_abl$k.so \
+#       kmergutsjava_amd/csrc/kmerguts_hip.hip -lz -lpthread; done; git apply -R tools/tag_ablate.patch
+# KG_ABL bits: 1 no candidate output (so no verification / placement either), 2 no tag compare, 4 synthetic entries (no
+# entry stream from HBM), 8 no tag loads.  The results of a variant are wrong by construction; only times are read.
 out=gpurun_out/r02/abl; mkdir -p $out
 export TMPDIR=/tmp SW_REPS=3
 for k in 0 1 3 5 9 13; do
