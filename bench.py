@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--num-sigs", type=int, default=1_400_303_159, help="signature table slots (x 24 B)")
     ap.add_argument("--load", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-threaded CPU row (0 = min(16, cores available); 1 = skip the row)")
     ap.add_argument("--cpu-sample-bp", type=int, default=100_000_000,
                     help="prefix of the contig list the CPU baseline is timed on (BASELINE.md section 3: >= 100 Mbp, "
                          "in batches of <= 20 M query k-mers)")
@@ -271,6 +272,38 @@ def cpu_baseline(args, rec, seq, off, tab):
     phases = o["t_prepare"] + o["t_lookup"] + o["t_group"]
     log("[bench] cpu_baseline: %d residues in %.1f s (prepare %.1f, lookup %.1f, group %.1f)" %
         (o["residues"], wall, o["t_prepare"], o["t_lookup"], o["t_group"]))
+    # second row (cpu_baseline.all_cores): what the host can do when it drops the reference's plan -- the same prefix cut into one group of whole
+    # contigs per thread, each group through the restatement with direct hash probing instead of the sorted merge-join
+    # (ctypes releases the GIL: the groups run in parallel).  Records compared with the single-thread run above.
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(args.cpu_threads or min(16, avail), n))          # 16 = a one-GPU box's share of the host's cores
+    all_cores = None
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        lens = sample_off[1:] - sample_off[:-1]
+        cuts = np.searchsorted(np.cumsum(lens), np.arange(1, threads) * (int(sample_off[-1]) / threads), side="left")
+        bounds = np.unique(np.concatenate([[0], cuts, [n]]))
+
+        def part(k):
+            a, b = int(bounds[k]), int(bounds[k + 1])
+            return kgo.run(host.numpy(), sample[int(sample_off[a]):int(sample_off[b])], sample_off[a:b + 1] - sample_off[a],
+                           lookup_mode=1)
+        t0 = time.time()
+        with ThreadPoolExecutor(len(bounds) - 1) as ex:
+            parts = list(ex.map(part, range(len(bounds) - 1)))
+        wall_mt = time.time() - t0
+        def rebased(kind):
+            out = []
+            for k, q in enumerate(parts):
+                rec = q[kind].copy()
+                rec["container"] += 6 * int(bounds[k])
+                out.append(rec.tobytes())
+            return b"".join(out)
+        same_mt = rebased("hits") == o["hits"].tobytes() and rebased("calls") == o["calls"].tobytes()
+        all_cores = {"value": o["residues"] / wall_mt, "unit": "residues/s", "cores": len(bounds) - 1, "kind": "port",
+                     "seconds": wall_mt, "records_identical_to_single_thread": bool(same_mt),
+                     "sample": "the same prefix, one group of whole contigs per thread, direct hash probing (no sort, no merge-join)"}
+        log("[bench] cpu_baseline (all cores): %d threads, %.2f s -> %.3g residues/s" % (len(bounds) - 1, wall_mt, all_cores["value"]))
     # parity of the full-size scan (same strategy as the timed steps)
     with tab.scan(None, off, hotpath.Params(), device_ptr=seq.data_ptr()) as r:
         n_chunks = max(1, r.stats["part_chunks"])
@@ -298,7 +331,7 @@ def cpu_baseline(args, rec, seq, off, tab):
                       "contig mix against the same table; C restatement of the reference's materialise -> sort by "
                       "(value %% numSigs, value) -> streamed merge-join -> gatherHits, single thread"
                       % (n, int(sample_off[-1]), o["residues"], o["windows_valid"]),
-            "seconds": phases, "cpu": _cpu_model(), "host_threads_available": os.cpu_count(),
+            "seconds": phases, "cpu": _cpu_model(), "host_threads_available": os.cpu_count(), "all_cores": all_cores,
             "phases_s": {"preparation": o["t_prepare"], "lookup": o["t_lookup"], "grouping": o["t_group"]}}
 
 
