@@ -7,11 +7,11 @@ for kv in "$@"; do export "$kv"; done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 tools/one_scan.py > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
 find $out -type f ! -name "*kernel_stats.csv" ! -name run.log -delete
 python3 - $out "$tag" <<'PY'
-import csv,sys,json,glob
+import csv,sys,json,glob,os
 out,tag=sys.argv[1],sys.argv[2]
 f=glob.glob(out+'/**/*kernel_stats.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
-keys=['bucket_tag','part_scatter','verify_kernel','place_unordered','row_info','rows_from']
+keys=os.environ.get('KSTAT_KEYS','bucket_tag,part_scatter,verify_kernel,place_unordered,row_info,rows_from').split(',')
 d={}
 for r in rows:
     for k in keys:
