@@ -540,15 +540,17 @@ __device__ __forceinline__ void chunk_finish(const UListState &u, uint32_t *__re
 }
 
 // Tag pass work distribution: the workgroups with blockIdx % 8 == x (one XCD under round-robin placement --
-// measured, tools/xcd_affinity.hip; speed only, never correctness) walk the buckets b % 8 == x in order and take
-// the bucket's regions one at a time from a per-bucket counter, so an XCD's L2 holds one bucket's tags (two at a
-// hand-over).
+// measured, tools/xcd_affinity.hip; speed only, never correctness) draw tickets from ONE counter per group: ticket t
+// is hand-out t % n_grabs of the group's bucket t / n_grabs, so the group walks the buckets b % 8 == x in order, one
+// region at a time, and an XCD's L2 holds one bucket's tags (two at a hand-over).  (A counter per bucket cost every
+// workgroup one more round trip per bucket -- the draw that finds the bucket exhausted: 0.15-0.25 ms of a 100-125 Mbp
+// batch, nothing at 1 Gbp; profiles/r02_pipeline.md section 5.)
 template <bool COUNTERS>
 __global__ __launch_bounds__(256) void bucket_tag_kernel(
     const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, const uint64_t *__restrict__ ent,
     const uint32_t *__restrict__ fill, uint32_t n_regions, uint32_t cap, uint32_t n_buckets, uint32_t shift,
     uint32_t grab /* entry slots per hand-out, multiple of 256 * kProbeN */,
-    uint32_t *next_region /* [n_buckets], zeroed */,
+    uint32_t *next_region /* ticket counter of group x at [32 * x], zeroed */,
     CandRec *__restrict__ cand, uint32_t *__restrict__ cand_used, unsigned long long *cand_cursor, uint64_t cand_cap,
     unsigned long long *ctr)
 {
@@ -565,81 +567,91 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
     const uint32_t kGrab = grab;
     const uint32_t grabs_per_region = (cap + kGrab - 1) / kGrab;
     const uint32_t n_grabs = n_regions * grabs_per_region;
-    for (uint32_t b = blockIdx.x & 7u; b < n_buckets; b += 8) {
-        for (;;) {
-            __syncthreads();
-            if (threadIdx.x == 0) s_region = atomicAdd(&next_region[b], 1u);
-            __syncthreads();
-            const uint32_t g = s_region;
-            if (g >= n_grabs) break;                    // bucket exhausted (uniform): next bucket of this group
-            const uint32_t w = g / grabs_per_region, g0 = (g % grabs_per_region) * kGrab;
-            const uint32_t n = min(fill[(uint64_t)b * n_regions + w], cap);     // (bulk appends may have run past the region)
-            const uint64_t *src = ent + ((uint64_t)b * n_regions + w) * cap;
-            for (uint32_t c0 = g0; c0 < n && c0 < g0 + kGrab; c0 += 256u * N) {
-                uint64_t home[N], cur[N];
-                uint32_t id[N], quo[N], fp[N], skip[N];
-                bool valid[N];
-                Tags16 tg[N];
-                // all entry loads first, then all tag loads: N independent L2 requests in flight per lane (loads
-                // complete in order, so interleaving entry and tag loads serialises them)
-                uint64_t ev[N];
+    const uint32_t xg = blockIdx.x & 7u;
+    const uint32_t n_tickets = xg < n_buckets ? ((n_buckets - xg + 7u) / 8u) * n_grabs : 0u;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_region = atomicAdd(&next_region[xg * 32u], 1u);
+        __syncthreads();
+        const uint32_t tk = s_region;
+        if (tk >= n_tickets) break;                 // the group's buckets are exhausted
+        const uint32_t b = xg + 8u * (tk / n_grabs), g = tk % n_grabs;
+        const uint32_t w = g / grabs_per_region, g0 = (g % grabs_per_region) * kGrab;
+        // the region's fill is requested together with its first batch of entries (slots below cap are mapped; what lies
+        // behind the fill is discarded below): one round trip less per hand-out
+        const uint32_t fraw = fill[(uint64_t)b * n_regions + w];
+        uint32_t n = cap;                               // until the fill has arrived
+        const uint64_t *src = ent + ((uint64_t)b * n_regions + w) * cap;
+        for (uint32_t c0 = g0; c0 < n && c0 < g0 + kGrab; c0 += 256u * N) {
+            const uint32_t bound = n;
+            uint64_t home[N], cur[N];
+            uint32_t id[N], quo[N], fp[N], skip[N];
+            bool valid[N];
+            Tags16 tg[N];
+            // all entry loads first, then all tag loads: N independent L2 requests in flight per lane (loads
+            // complete in order, so interleaving entry and tag loads serialises them)
+            uint64_t ev[N];
 #pragma unroll
-                for (int k = 0; k < N; k++) {
-                    const uint32_t i = c0 + (uint32_t)k * 256u + threadIdx.x;
-                    ev[k] = i < n ? __builtin_nontemporal_load(src + i) : kEntInvalid;
-                }
+            for (int k = 0; k < N; k++) {
+                const uint32_t i = c0 + (uint32_t)k * 256u + threadIdx.x;
+                ev[k] = i < bound ? __builtin_nontemporal_load(src + i) : kEntInvalid;
+            }
+            if (c0 == g0) {
+                uint32_t f = fraw;
+                asm volatile("; fill first used here" : "+s"(f));       // (keeps the scalar wait behind the entry loads)
+                n = min(f, cap);                                        // (bulk appends may have run past the region)
+            }
 #pragma unroll
-                for (int k = 0; k < N; k++) {
-                    const uint64_t e = ev[k];
-                    valid[k] = e != kEntInvalid;
-                    const uint32_t low = (uint32_t)e;
-                    id[k] = (uint32_t)(e >> 32);
-                    home[k] = ((uint64_t)b << shift) | (low & ((1u << shift) - 1u));
-                    quo[k] = low >> shift;
-                    fp[k] = tag_qs(quo[k], home[k]);
-                    cur[k] = probe_window(home[k], &skip[k]);
-                    if (valid[k]) tg[k] = load_tags(tags + cur[k]);
-                }
-                // a window that holds neither an empty slot nor the fingerprint (2 % of the probes: straddling windows,
-                // long clusters) is not walked here: it goes to the candidate list with kWalkOn set and the verify pass
-                // continues the walk.  This keeps the hot loop free of the generic walk.
-                uint32_t candm = 0, walkm = 0;
+            for (int k = 0; k < N; k++) {
+                const uint64_t e = c0 + (uint32_t)k * 256u + threadIdx.x < n ? ev[k] : kEntInvalid;
+                valid[k] = e != kEntInvalid;
+                const uint32_t low = (uint32_t)e;
+                id[k] = (uint32_t)(e >> 32);
+                home[k] = ((uint64_t)b << shift) | (low & ((1u << shift) - 1u));
+                quo[k] = low >> shift;
+                fp[k] = tag_qs(quo[k], home[k]);
+                cur[k] = probe_window(home[k], &skip[k]);
+                if (valid[k]) tg[k] = load_tags(tags + cur[k]);
+            }
+            // a window that holds neither an empty slot nor the fingerprint (2 % of the probes: straddling windows,
+            // long clusters) is not walked here: it goes to the candidate list with kWalkOn set and the verify pass
+            // continues the walk.  This keeps the hot loop free of the generic walk.
+            uint32_t candm = 0, walkm = 0;
 #pragma unroll
-                for (int k = 0; k < N; k++) {
-                    if (valid[k]) {
-                        bool emp;
-                        const int i = first_stop(tg[k], fp[k], &emp, skip[k]);
-                        cur[k] += (uint64_t)i;
-                        if (i == 16) { candm |= 1u << k; walkm |= 1u << k; }
-                        else if (!emp) candm |= 1u << k;
-                        else {
-                            if (cur[k] >= limit) ran_off = true;   // the "empty slot" is the padding behind the last record
-                            if (COUNTERS) ctr_slots += (cur[k] < limit ? cur[k] + 1 : limit) - home[k];
-                        }
+            for (int k = 0; k < N; k++) {
+                if (valid[k]) {
+                    bool emp;
+                    const int i = first_stop(tg[k], fp[k], &emp, skip[k]);
+                    cur[k] += (uint64_t)i;
+                    if (i == 16) { candm |= 1u << k; walkm |= 1u << k; }
+                    else if (!emp) candm |= 1u << k;
+                    else {
+                        if (cur[k] >= limit) ran_off = true;   // the "empty slot" is the padding behind the last record
+                        if (COUNTERS) ctr_slots += (cur[k] < limit ? cur[k] + 1 : limit) - home[k];
                     }
                 }
-                // candidates -> list
-                uint32_t cnt[N], rank[N], total = 0;
+            }
+            // candidates -> list
+            uint32_t cnt[N], rank[N], total = 0;
 #pragma unroll
-                for (int k = 0; k < N; k++) {
-                    const unsigned long long m = __ballot((candm >> k) & 1u);
-                    cnt[k] = (uint32_t)__popcll(m);
-                    rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    total += cnt[k];
-                }
-                if (total) {
-                    unsigned long long at = chunk_reserve(u, total, cand_used, cand_cursor, cand_cap, lane);
-                    if (at != ~0ull) {
+            for (int k = 0; k < N; k++) {
+                const unsigned long long m = __ballot((candm >> k) & 1u);
+                cnt[k] = (uint32_t)__popcll(m);
+                rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                total += cnt[k];
+            }
+            if (total) {
+                unsigned long long at = chunk_reserve(u, total, cand_used, cand_cursor, cand_cap, lane);
+                if (at != ~0ull) {
 #pragma unroll
-                        for (int k = 0; k < N; k++) {
-                            if ((candm >> k) & 1u) {
-                                CandRec c;
-                                c.val = (uint64_t)quo[k] * num_sigs + home[k];          // the k-mer value, candidates only
-                                c.id = id[k]; c.walked = (uint32_t)(cur[k] - home[k]) | (((walkm >> k) & 1u) ? kWalkOn : 0u);
-                                cand[at + rank[k]] = c;
-                            }
-                            at += cnt[k];
+                    for (int k = 0; k < N; k++) {
+                        if ((candm >> k) & 1u) {
+                            CandRec c;
+                            c.val = (uint64_t)quo[k] * num_sigs + home[k];          // the k-mer value, candidates only
+                            c.id = id[k]; c.walked = (uint32_t)(cur[k] - home[k]) | (((walkm >> k) & 1u) ? kWalkOn : 0u);
+                            cand[at + rank[k]] = c;
                         }
+                        at += cnt[k];
                     }
                 }
             }

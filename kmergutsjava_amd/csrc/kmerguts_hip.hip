@@ -817,7 +817,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if ((rc = sc.get(&d_fill, (size_t)n_regions_total * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_ovf_ent, (size_t)ovf_cap * kg::kGroup * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_ovf_bucket, (size_t)ovf_cap * n_chunks_p))) return rc;
-        const size_t next_stride = (size_t)part_buckets + 8;
+        const size_t next_stride = std::max<size_t>((size_t)part_buckets + 8, 256);   // tag pass: one hand-out counter per XCD group, 128 B apart
         if ((rc = sc.get(&d_next, next_stride * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_ovfc, 8 * kMaxChunks))) return rc;       // per chunk: [0] overflow groups, [1] low-complexity blocks
         uint32_t *d_lowc = nullptr;                                    // block numbers set aside by the scatter pass
