@@ -866,6 +866,26 @@ __global__ void container_starts_kernel(const uint32_t *ibase, uint32_t n_seqs, 
 }
 
 // ---------------------------------------------------------------------------------------
+// Several buffers cleared by one launch (a scan starts with seven small clears and one large one: as separate
+// memsets they cost ~10 us each, mostly launch gaps).  Sizes in 4-byte words; pointers 4-byte aligned.
+struct ClearList { uint32_t *p[8]; uint64_t words[8]; int n; };
+
+__global__ __launch_bounds__(256) void clear_many_kernel(ClearList l)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (int k = 0; k < l.n; k++) {
+        uint32_t *p = l.p[k];
+        const uint64_t w = l.words[k];
+        const uint64_t head = min(w, (uint64_t)((16u - ((uintptr_t)p & 15u)) & 15u) / 4u);      // words up to 16-byte alignment
+        const uint64_t quads = (w - head) / 4;
+        uint4 *q = reinterpret_cast<uint4 *>(p + head);
+        for (uint64_t i = tid; i < quads; i += stride) q[i] = make_uint4(0, 0, 0, 0);
+        for (uint64_t i = tid; i < head; i += stride) p[i] = 0;
+        for (uint64_t i = head + quads * 4 + tid; i < w; i += stride) p[i] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // tag array from the 24-byte records (one pass over the table at load time)
 __global__ void build_tags_kernel(const uint8_t *entries, uint64_t limit, uint64_t n_tags, uint64_t num_sigs, uint64_t magic,
                                   uint8_t *tags, unsigned long long *occupied)

@@ -180,6 +180,9 @@ struct kg_table {
     double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
     size_t scatter_lds[2] = {0, 0};  // dynamic LDS the scatter kernel (DNA / protein) has been allowed so far
     hipEvent_t ev[8] = {};
+    // Pinned host words for the few counters a scan reads back (a hipMemcpyAsync to pageable memory blocks the host per
+    // copy; to pinned memory it does not): [0..47] d_pc, [48..79] d_ovfc (as 64 x u32), [80..87] d_totals, [88] CALL total
+    uint64_t *h_pin = nullptr;
     DevCache cache;
     PinCache pins;
 };
@@ -268,6 +271,7 @@ int table_new(int device, kg_table **out)
     if (!t) return fail(KG_ERR_NOMEM, "out of host memory");
     t->device = device;
     hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&t->h_pin, 96 * 8);
     for (auto &ev : t->ev)
         if (e == hipSuccess) e = hipEventCreate(&ev);               // (a table-less context of kg_aggregate_hits uses them too)
     if (e != hipSuccess) { kg_table_close(t); return fail(KG_ERR_DEVICE, std::string("hipStreamCreate / hipEventCreate: ") + hipGetErrorString(e)); }
@@ -518,6 +522,7 @@ void kg_table_close(kg_table *t)
     if (t->d_tags) (void)hipFree(t->d_tags);
     t->cache.release_all();
     t->pins.release_all();
+    if (t->h_pin) (void)hipHostFree(t->h_pin);
     for (auto &e : t->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : t->pev)
@@ -587,11 +592,14 @@ struct Scratch {
 // gatherHits / processSetOfHits / the OTU buffer (KGJ:385-524) over res->d_hits + res->d_chs: fills the CALL, OTU and event
 // arrays of res.  d_partial: prefix-sum scratch for n_cont items, d_totals[4]: the CALL total.  otu_init (device, one record
 // per sequence, or null): the oICounts buffers the sequences start with (kg_aggregate_hits; the scan starts them empty).
+// Everything is enqueued on t->stream and nothing is waited for: calls[] is allocated for the most CALLs n_hits records can
+// make (n_hits / minHits), so the host does not need the CALL total before the records are compacted; the total arrives in
+// t->h_pin[kPinCalls] once the caller has synchronised the stream.
+constexpr int kPinCalls = 88;
 int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc, int64_t n_seqs, uint64_t n_cont, uint64_t n_hits,
-                    uint32_t PER, uint64_t *d_partial, uint64_t *d_totals, const kg_otu *d_otu_init, uint64_t *n_calls_out)
+                    uint32_t PER, uint64_t *d_partial, uint64_t *d_totals, const kg_otu *d_otu_init)
 {
     int rc;
-    uint64_t n_calls = 0;
     {
         kg::AggParams ap;
         ap.min_hits = p->min_hits; ap.min_weighted_hits = p->min_weighted_hits;
@@ -619,9 +627,8 @@ int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc
             HIP_TRY(hipGetLastError());
         }
         if ((rc = prefix_sum(t, d_ccnt, n_cont, d_coff, d_partial, d_totals + 4))) return rc;
-        uint64_t h_calls = 0;
-        HIP_TRY(hipMemcpyAsync(&h_calls, d_totals + 4, 8, hipMemcpyDeviceToHost, t->stream));
-        // the OTU votes need the voter marks only: they run while the host waits for the CALL total
+        t->h_pin[kPinCalls] = 0;
+        if (n_cont) HIP_TRY(hipMemcpyAsync(t->h_pin + kPinCalls, d_totals + 4, 8, hipMemcpyDeviceToHost, t->stream));
         if (n_seqs) {
             const uint32_t spw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (uint64_t)n_seqs / (1u << 17)));
             hipLaunchKernelGGL(kg::otu_wave_kernel, dim3((uint32_t)((((uint64_t)n_seqs + spw - 1) / spw + 3) / 4)), dim3(256), 0, t->stream,
@@ -629,10 +636,8 @@ int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc
         }
         hipLaunchKernelGGL(kg::call_starts_kernel, dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream, d_coff,
                            n_cont, d_totals + 4, res->d_ccs);
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        n_calls = n_cont ? h_calls : 0;
-        if ((rc = dalloc(t, (void **)&res->d_calls, n_calls * sizeof(kg_call)))) return rc;
-        if (n_cont && n_calls) {
+        if ((rc = dalloc(t, (void **)&res->d_calls, (size_t)(n_hits / (uint64_t)p->min_hits + 1) * sizeof(kg_call)))) return rc;
+        if (n_cont) {
             if (n_cont < (1u << 17))
                 hipLaunchKernelGGL((kg::compact_calls_kernel<64>), dim3((uint32_t)((n_cont * 64 + 255) / 256)), dim3(256), 0, t->stream,
                                    d_staged, res->d_chs, d_ccnt, d_coff, (uint32_t)n_cont, (uint32_t)p->min_hits, res->d_calls);
@@ -642,7 +647,6 @@ int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc
         }
         HIP_TRY(hipGetLastError());
     }
-    *n_calls_out = n_calls;
     return KG_OK;
 }
 
@@ -827,7 +831,6 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if ((rc = sc.get(&d_pc, 48))) return rc;
         if ((rc = sc.get(&d_partial_c, partial_stride * n_chunks_p))) return rc;
         unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
-        HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
         const size_t lds = kg::scatter_lds_bytes<AA>(part_buckets);
         if (t->scatter_lds[AA ? 1 : 0] < lds) {         // once per table (and geometry): the call costs tens of microseconds
             HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -861,13 +864,21 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             if ((rc = dalloc(t, (void **)&d_cused, cused_stride * n_chunks_p * 4))) { sc.adopt(d_ulist); return rc; }
             if ((rc = dalloc(t, (void **)&d_cand, ccap * n_chunks_p * sizeof(kg::CandRec)))) { sc.adopt(d_ulist); sc.adopt(d_cused); return rc; }
             if ((rc = dalloc(t, (void **)&d_candused, candused_stride * n_chunks_p * 4))) { sc.adopt(d_ulist); sc.adopt(d_cused); sc.adopt(d_cand); return rc; }
-            HIP_TRY(hipMemsetAsync(d_cused, 0, cused_stride * n_chunks_p * 4, t->stream));
-            HIP_TRY(hipMemsetAsync(d_candused, 0, candused_stride * n_chunks_p * 4, t->stream));
-            HIP_TRY(hipMemsetAsync(d_pc, 0, 48 * 8, t->stream));
-            HIP_TRY(hipMemsetAsync(d_totals, 0, 32, t->stream));          // total and both counters of a re-run start over
-            HIP_TRY(hipMemsetAsync(d_ovfc, 0, 8 * kMaxChunks * 4, t->stream));
-            HIP_TRY(hipMemsetAsync(d_next, 0, next_stride * n_chunks_p * 4, t->stream));
-            HIP_TRY(hipMemsetAsync(d_masks, 0, n_rows * 8, t->stream));
+            {   // one launch for all clears (d_totals: totals, counters and flags of a re-run start over)
+                kg::ClearList cl;
+                cl.n = 7;
+                cl.p[0] = d_cused; cl.words[0] = (uint64_t)cused_stride * n_chunks_p;
+                cl.p[1] = d_candused; cl.words[1] = (uint64_t)candused_stride * n_chunks_p;
+                cl.p[2] = reinterpret_cast<uint32_t *>(d_pc); cl.words[2] = 48 * 2;
+                cl.p[3] = reinterpret_cast<uint32_t *>(d_totals); cl.words[3] = 16;
+                cl.p[4] = d_ovfc; cl.words[4] = 8 * kMaxChunks;
+                cl.p[5] = d_next; cl.words[5] = (uint64_t)next_stride * n_chunks_p;
+                cl.p[6] = reinterpret_cast<uint32_t *>(d_masks); cl.words[6] = (uint64_t)n_rows * 2;
+                cl.p[7] = nullptr; cl.words[7] = 0;
+                const uint64_t most = std::max<uint64_t>(cl.words[6], 1) / 4;
+                hipLaunchKernelGGL(kg::clear_many_kernel, dim3((uint32_t)std::min<uint64_t>(4096, (most + 255) / 256 + 1)), dim3(256), 0,
+                                   t->stream, cl);
+            }
             HIP_TRY(hipEventRecord(t->pev[16], t->stream));               // fork: stream2 starts behind the clears
             HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[16], 0));
             HIP_TRY(hipStreamWaitEvent(t->stream3, t->pev[16], 0));
@@ -941,13 +952,15 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             HIP_TRY(hipStreamWaitEvent(t->stream, t->pev[18], 0));
             HIP_TRY(hipEventRecord(t->ev[7], t->stream));
             st.scan_launches++;
-            uint64_t h_pc[48];
-            uint32_t h_ovf[8 * kMaxChunks];
+            const uint64_t *h_pc = t->h_pin;
+            const uint32_t *h_ovf = reinterpret_cast<const uint32_t *>(t->h_pin + 48);
+            static_assert(8 * kMaxChunks * 4 <= 32 * 8, "overflow counters must fit their pinned words");
             HIP_TRY(hipEventRecord(t->ev[2], t->stream));                 // end of the scan stage (of this attempt)
-            HIP_TRY(hipMemcpyAsync(h_pc, d_pc, sizeof h_pc, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipMemcpyAsync(h_ovf, d_ovfc, sizeof h_ovf, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 48, hipMemcpyDeviceToHost, t->stream));   // one host round trip for all three
+            HIP_TRY(hipMemcpyAsync(t->h_pin, d_pc, 48 * 8, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(t->h_pin + 48, d_ovfc, 8 * kMaxChunks * 4, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(t->h_pin + 80, d_totals, 48, hipMemcpyDeviceToHost, t->stream));   // pinned: one host round trip for all three
             HIP_TRY(hipStreamSynchronize(t->stream));
+            for (int k = 0; k < 6; k++) h_tot[k] = t->h_pin[80 + k];
             uint64_t need_u = 0, need_c = 0;
             uint32_t max_ovf = 0, guard = 0;
             for (uint32_t c = 0; c < n_chunks_p; c++) {
@@ -1074,12 +1087,12 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
     HIP_TRY(hipEventRecord(t->ev[3], t->stream));
 
     // ---- aggregation: CALL records and OTU votes ----
-    uint64_t n_calls = 0;
-    if (!(p->flags & KG_F_SKIP_AGGREGATE))
-        if ((rc = aggregate_stage(t, p, res, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, nullptr, &n_calls))) return rc;
-    st.n_calls = (int64_t)n_calls;
+    const bool aggregate = !(p->flags & KG_F_SKIP_AGGREGATE);
+    if (aggregate)
+        if ((rc = aggregate_stage(t, p, res, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, nullptr))) return rc;
     HIP_TRY(hipEventRecord(t->ev[4], t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
+    st.n_calls = aggregate ? (int64_t)t->h_pin[kPinCalls] : 0;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, t->ev[1], t->ev[2])); st.ms_scan = ms;
     HIP_TRY(hipEventElapsedTime(&ms, t->ev[2], t->ev[3])); st.ms_order = ms;
@@ -1199,10 +1212,10 @@ int kg_aggregate_hits(int device, const kg_params *p, const kg_hit *hits, const 
         if (n_hits) HIP_TRY(hipMemcpyAsync(r->d_hits, hits, n_hits * sizeof(kg_hit), hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(r->d_chs, container_hit_start, (n_cont + 1) * 8, hipMemcpyHostToDevice, t->stream));
         if (d_init) HIP_TRY(hipMemcpyAsync(d_init, otu_init, (size_t)n_seqs * sizeof(kg_otu), hipMemcpyHostToDevice, t->stream));
-        uint64_t n_calls = 0;
-        if ((rc2 = aggregate_stage(t, p, r, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, d_init, &n_calls))) return rc2;
+        if ((rc2 = aggregate_stage(t, p, r, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, d_init))) return rc2;
         HIP_TRY(hipStreamSynchronize(t->stream));
-        r->st.n_seqs = n_seqs; r->st.n_containers = (int64_t)n_cont; r->st.n_hits = (int64_t)n_hits; r->st.n_calls = (int64_t)n_calls;
+        r->st.n_seqs = n_seqs; r->st.n_containers = (int64_t)n_cont; r->st.n_hits = (int64_t)n_hits;
+        r->st.n_calls = (int64_t)t->h_pin[kPinCalls];
         r->st.windows_valid = -1; r->st.slots_inspected = -1;
         return KG_OK;
     }();
