@@ -113,11 +113,19 @@ __device__ __forceinline__ uint64_t split_halves(uint32_t hi, uint32_t lo, const
 // 8-bit fingerprint of a k-mer, from its (q, slot) form: 24-bit multiplies only; the byte is taken from the
 // middle of the products, where every low input bit has spread.  Keys that share a home slot differ in q and
 // never collide; neighbours collide at the ideal 1/255 (tools/notes in profiles/r01_partition_path.md).
+// (as the instruction: in the probe loops the compiler turns __umul24 by a constant into v_mul_lo_u32, quarter rate)
+__device__ __forceinline__ uint32_t mul24(uint32_t x, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(c), "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t tag_qs(uint64_t q, uint64_t slot)
 {
     const uint32_t q32 = (uint32_t)q ^ (uint32_t)(q >> 32);
-    const uint32_t h = __umul24((uint32_t)slot, 0x9E3779u) ^ __umul24((uint32_t)(slot >> 24), 0x85EBCBu) ^
-                       __umul24(q32 ^ (q32 >> 19), 0xC2B2AFu);
+    const uint32_t h = mul24((uint32_t)slot, 0x9E3779u) ^ mul24((uint32_t)(slot >> 24), 0x85EBCBu) ^
+                       mul24(q32 ^ (q32 >> 19), 0xC2B2AFu);
     const uint32_t t = (h >> 16) & 0xFFu;
     return t == kTagEmpty ? 0xFEu : t;
 }
@@ -149,7 +157,7 @@ __device__ __forceinline__ Tags16 load_tags(const uint8_t *p)
 // none.  *is_empty tells which.
 __device__ __forceinline__ int first_stop(const Tags16 &x, uint32_t fp, bool *is_empty, uint32_t skip = 0)
 {
-    const uint32_t fpw = fp * 0x01010101u;
+    const uint32_t fpw = __builtin_amdgcn_perm(0u, fp, 0u);     // fp (one byte) in all four bytes
     uint32_t e0 = zero_bytes(~x.w[0]), e1 = zero_bytes(~x.w[1]), e2 = zero_bytes(~x.w[2]), e3 = zero_bytes(~x.w[3]);
     uint32_t f0 = zero_bytes(x.w[0] ^ fpw), f1 = zero_bytes(x.w[1] ^ fpw), f2 = zero_bytes(x.w[2] ^ fpw), f3 = zero_bytes(x.w[3] ^ fpw);
     uint64_t elo = ((uint64_t)e1 << 32) | e0, ehi = ((uint64_t)e3 << 32) | e2;

@@ -513,7 +513,9 @@ __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, 
 //                 becomes a 16-byte candidate record {value, id, slots walked}.  Never touches the 24-byte records.
 //   verify pass : one lane per candidate: fetch the record (random line from HBM, thousands in flight), compare the
 //                 key, emit the hit; a fingerprint collision keeps walking (generic, rare).
-struct CandRec { uint64_t val; uint32_t id; uint32_t walked; };   // walked: slots from the home slot; kWalkOn: no record to check yet
+// home + quo * numSigs = the k-mer value (numSigs < 2^31 on this path; the multiplication is left to the verify pass:
+// v_mad_u64_u32 runs at a quarter of the VALU rate and the tag pass would pay it in every batch that has a candidate)
+struct CandRec { uint32_t home, quo, id, walked; };   // walked: slots from the home slot; kWalkOn: no record to check yet
 constexpr uint32_t kWalkOn = 0x80000000u;
 static_assert(sizeof(CandRec) == 16, "CandRec must be 16 bytes");
 
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                     for (int k = 0; k < N; k++) {
                         if ((candm >> k) & 1u) {
                             CandRec c;
-                            c.val = (uint64_t)quo[k] * num_sigs + home[k];          // the k-mer value, candidates only
+                            c.home = (uint32_t)home[k]; c.quo = quo[k];
                             c.id = id[k]; c.walked = (uint32_t)(cur[k] - home[k]) | (((walkm >> k) & 1u) ? kWalkOn : 0u);
                             cand[at + rank[k]] = c;
                         }
@@ -690,10 +692,10 @@ __global__ __launch_bounds__(256) void verify_kernel(
         for (uint32_t k0 = 0; k0 < used; k0 += 64) {
             const bool act = k0 + (uint32_t)lane < used;
             CandRec r;
-            r.val = 0; r.id = 0; r.walked = 0;
+            r.home = 0; r.quo = 0; r.id = 0; r.walked = 0;
             if (act) r = cand[(uint64_t)c * kUChunk + k0 + lane];
-            uint64_t quo;
-            const uint64_t home = split_value(r.val, tab, &quo);
+            const uint64_t quo = r.quo, home = r.home;
+            const uint64_t val = quo * num_sigs + home;
             uint64_t s = home + (r.walked & ~kWalkOn);
             bool found = false;
             Entry e;
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(256) void verify_kernel(
             if (act) {
                 if (!(r.walked & kWalkOn)) {               // a fingerprint match at s: check the record
                     e = load_entry(tab, s);
-                    found = e.key == (int64_t)r.val;
+                    found = e.key == (int64_t)val;
                     if (!found) s += 1;                    // fingerprint collision: keep walking (KGJ:944-1034 semantics)
                 }
                 if (!found) {
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(256) void verify_kernel(
                         s += (uint64_t)i;
                         if (emp) { if (s >= limit) ran_off = true; break; }
                         e = load_entry(tab, s);
-                        if (e.key == (int64_t)r.val) { found = true; break; }
+                        if (e.key == (int64_t)val) { found = true; break; }
                         s += 1;
                     }
                 }
