@@ -121,6 +121,9 @@ typedef struct kg_stats {
                                  /* reference's table stream throws EOFException and its lookup ends with            */
                                  /* "Error: null" instead of "Kmers found: ..." (KGJ:799-802, 1031-1033, 1097-1126); */
                                  /* the records are the same either way (EOF == not found)                           */
+    int32_t agg_pieces;          /* pieces beyond the first that long containers were cut into for gatherHits (cuts  */
+                                 /* at gaps > maxGap, where the reference's list restarts anyway: KGJ:477-484)       */
+    int32_t reserved0;
 } kg_stats;
 
 typedef struct kg_table  kg_table;

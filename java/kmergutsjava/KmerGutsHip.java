@@ -40,11 +40,11 @@ public interface KmerGutsHip extends Library {
         public float ms_scan, ms_order, ms_aggregate, ms_total;
         public int scan_launches, partitioned;
         public float ms_part_scatter, ms_part_tag, ms_part_verify;
-        public int fallback, part_chunks, part_buckets, part_shift, lookup_ran_off;
+        public int fallback, part_chunks, part_buckets, part_shift, lookup_ran_off, agg_pieces, reserved0;
         @Override protected List<String> getFieldOrder() {
             return Arrays.asList("n_seqs", "n_containers", "n_blocks", "n_hits", "n_calls", "residues", "windows",
                     "windows_valid", "slots_inspected", "table_bytes", "ms_scan", "ms_order", "ms_aggregate",
-                    "ms_total", "scan_launches", "partitioned", "ms_part_scatter", "ms_part_tag", "ms_part_verify", "fallback", "part_chunks", "part_buckets", "part_shift", "lookup_ran_off");
+                    "ms_total", "scan_launches", "partitioned", "ms_part_scatter", "ms_part_tag", "ms_part_verify", "fallback", "part_chunks", "part_buckets", "part_shift", "lookup_ran_off", "agg_pieces", "reserved0");
         }
     }
 

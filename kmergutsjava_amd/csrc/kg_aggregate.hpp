@@ -164,34 +164,73 @@ struct EvMasks {
     }
 };
 
-__global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restrict__ hits, const int64_t *__restrict__ chs,
-                                                         uint32_t n_cont, AggParams p, uint8_t *acc, uint8_t *vote, uint8_t *tail_ev,
-                                                         uint32_t *call_cnt, kg_call *staged /* [n_hits / minHits + 1] */,
-                                                         uint32_t per_wave)
-{
-    // per_wave consecutive containers per wave: 1 for few long containers (contigs); more for millions of short ones
-    // (reads), where launching a wave per container would cost more than the work
-    const int lane = threadIdx.x & 63;
-    const uint32_t c_first = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6))) * per_wave;
-    // The wave's containers' extents in one coalesced load (per_wave <= 64).  Containers with fewer than two hits need
-    // no machine (minHits >= 2: no CALL; a single hit is simply accepted, KGJ:486-497): lanes settle them directly and
-    // the sequential part below visits only the others.
-    uint32_t my_begin = 0, my_end = 0;
-    const bool mine = (uint32_t)lane < per_wave && c_first + (uint32_t)lane < n_cont;
-    if (mine) { my_begin = (uint32_t)chs[c_first + lane]; my_end = (uint32_t)chs[c_first + lane + 1]; }
-    if (mine && my_end - my_begin < 2) {
-        call_cnt[c_first + lane] = 0;
-        tail_ev[c_first + lane] = 0;
-        if (my_end != my_begin) { acc[my_begin] = (uint8_t)KG_EV_ACCEPTED; vote[my_begin] = 0; }
-    }
-    uint64_t todo = __ballot(mine && my_end - my_begin >= 2);
-    while (todo) {
-    const int ci = __builtin_ctzll(todo);
-    todo &= todo - 1;
-    const uint32_t c = c_first + (uint32_t)ci;
-    const uint32_t begin = (uint32_t)rl((int32_t)my_begin, ci), end = (uint32_t)rl((int32_t)my_end, ci);
-    kg_call *calls = staged + begin / (uint32_t)p.min_hits;          // the container's staging range (see the header)
+// Long containers are cut into PIECES at static gaps.  One wave per container makes a 4.6 Mbp chromosome (six containers
+// of 10^5 hits) a chain of thousands of 64-record chunks: 3-11 ms of aggregation behind a 0.15 ms scan
+// (tools/ecoli_time.py).  With the default parameters (no -O, 0 <= maxGap, positions + maxGap below 2^31) a record that lies
+// more than maxGap behind its predecessor always finds the machine resetting (KGJ:477-484: the list's last member is at or
+// before the predecessor, so the gap rule fires; the list is processed or cleared and the record starts an empty one; no
+// carry is possible, see the gap branch below).  What happens behind such a record does not depend on what happened before
+// it, so another wave can start there.  piece_starts_kernel picks, per block of 2^pshift records of hits[], at most one such
+// record (the first among the block's first 256 records, at least half a block away from both ends of its container); a
+// unit = a container's first piece or the piece that starts in block u (calls_wave_kernel).  A unit that runs into the next
+// piece's first record does what the gap rule would do there (process or clear its list) and leaves the record's
+// RESET_BEFORE / CALL_BEFORE bits in before_ev[u] (merge_before_kernel ORs them into the record's event byte: two waves
+// would otherwise write one byte).  CALLs of a piece go to the staging range of its first record; compact_calls_kernel
+// walks a container's pieces in order.
+constexpr uint32_t kNoPiece = 0xFFFFFFFFu;
 
+__global__ __launch_bounds__(256) void piece_starts_kernel(const kg_hit *__restrict__ hits, const int64_t *__restrict__ chs,
+                                                           uint32_t n_hits, uint32_t pshift, int32_t max_gap,
+                                                           uint32_t *__restrict__ piece_start, uint32_t n_blocks)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t u = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (u >= n_blocks) return;
+    uint32_t found = kNoPiece;
+    const uint32_t blk = 1u << pshift, i0 = u << pshift;
+    if (u > 0 && i0 < n_hits) {
+        // a block inside a short container is not worth a piece: look at the container of the block's first record first
+        const uint32_t c0 = hits[i0].container;
+        const uint32_t lo0 = (uint32_t)chs[c0], hi0 = (uint32_t)chs[c0 + 1];
+        const bool long_enough = hi0 - lo0 >= 2u * blk || hi0 < i0 + blk;      // (or the block runs into the next container)
+        for (uint32_t j = 0; j < 256u && j < blk && found == kNoPiece && long_enough; j += 64) {
+            const uint32_t i = i0 + j + (uint32_t)lane;
+            bool gap = false;
+            if (i < n_hits && j + (uint32_t)lane < blk) {
+                const kg_hit a = hits[i - 1], b = hits[i];
+                gap = a.container == b.container && (int32_t)((uint32_t)a.from0InProt + (uint32_t)max_gap) < b.from0InProt;
+            }
+            const uint64_t m = __ballot(gap);
+            if (m) found = i0 + j + (uint32_t)__builtin_ctzll(m);
+        }
+    }
+    if (found != kNoPiece) {
+        const uint32_t c = hits[found].container;
+        const uint32_t lo = (uint32_t)chs[c], hi = (uint32_t)chs[c + 1];
+        if (found - lo < blk / 2 || hi - found < blk / 2) found = kNoPiece;      // pieces of at least half a block
+    }
+    if (lane == 0) piece_start[u] = found;
+}
+
+__global__ void merge_before_kernel(const uint32_t *__restrict__ piece_start, const uint8_t *__restrict__ before_ev, uint32_t n_blocks,
+                                    uint8_t *ev, unsigned long long *n_pieces)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ps = u < n_blocks ? piece_start[u] : kNoPiece;
+    if (ps != kNoPiece && before_ev[u]) ev[ps] |= before_ev[u];
+    const unsigned long long m = __ballot(ps != kNoPiece);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(n_pieces, (unsigned long long)__popcll(m));
+}
+
+// One unit: the records [begin, end) of container c, or up to the first record of the next piece.  calls = the unit's
+// staging range.  Returns the number of CALLs; *tail_out = the container's tail event when the unit reached `end`.
+__device__ __forceinline__ uint32_t walk_unit(const kg_hit *__restrict__ hits, const AggParams &p, uint8_t *acc, uint8_t *vote,
+                                              const uint32_t begin, const uint32_t end, const uint32_t c, kg_call *calls,
+                                              const uint32_t *__restrict__ piece_start, const uint32_t pshift, uint8_t *before_ev,
+                                              uint32_t *tail_out, bool *reached_end)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t stopped_at = kNoPiece;
     AggState s;
     s.lo = s.last = s.prev = begin;
     s.last_pos = s.last_fI = s.last_avg = s.prev_fI = 0;
@@ -201,12 +240,35 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
     // "no such chunk": a base no record index comes within 64 of (kg_scan takes < 2^32 - 256 hit records)
     pv.base = ppv.base = 0xFFFFFF00u; pv.mask = ppv.mask = 0; pv.fI = ppv.fI = pv.pos = ppv.pos = 0; pv.wt = ppv.wt = 0.f;
 
+    // the next chunk's fields are requested before the current chunk is worked on: a long unit is a chain of chunks
+    int32_t n_pos = 0, n_fI = 0, n_avg = 0;
+    float n_wt = 0.f;
+    if (begin + (uint32_t)lane < end) {
+        const kg_hit &h0 = hits[begin + lane];
+        n_pos = h0.from0InProt; n_fI = h0.fI; n_avg = h0.avgOffFromEnd; n_wt = h0.functionWt;
+    }
     for (uint32_t base = begin; base < end; base += 64) {
-        const int n = (int)min(64u, end - base);
+        int n = (int)min(64u, end - base);
+        if (piece_start) {                           // does another piece start inside this chunk?
+            const uint32_t u1 = base >> pshift, u2 = (base + (uint32_t)n - 1u) >> pshift;
+            const uint32_t s1 = piece_start[u1];
+            if (s1 > begin && s1 >= base && s1 < base + (uint32_t)n) stopped_at = s1;
+            if (u2 != u1) {
+                const uint32_t s2 = piece_start[u2];
+                if (s2 > begin && s2 < base + (uint32_t)n && s2 < stopped_at) stopped_at = s2;
+            }
+            if (stopped_at != kNoPiece) n = (int)(stopped_at - base);
+            if (n == 0) break;
+        }
         const uint32_t i = base + lane;
-        int32_t pos = 0, fI = 0, avg = 0;
-        float wt = 0.f;
-        if (lane < n) { pos = hits[i].from0InProt; fI = hits[i].fI; avg = hits[i].avgOffFromEnd; wt = hits[i].functionWt; }
+        int32_t pos = n_pos, fI = n_fI, avg = n_avg;
+        float wt = n_wt;
+        if (lane >= n) { pos = 0; fI = 0; avg = 0; wt = 0.f; }      // (a chunk cut short by the next piece)
+        n_pos = 0; n_fI = 0; n_avg = 0; n_wt = 0.f;
+        if (base + 64u + (uint32_t)lane < end) {
+            const kg_hit &h1 = hits[base + 64u + lane];
+            n_pos = h1.from0InProt; n_fI = h1.fI; n_avg = h1.avgOffFromEnd; n_wt = h1.functionWt;
+        }
         uint64_t accmask;
         uint64_t votes = 0;                          // records of this chunk whose vote counted towards a CALL
         EvMasks em = {0, 0, 0, 0, 0, 0};
@@ -324,31 +386,144 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
         ppv = pv;
         cu.mask = accmask;
         pv = cu;
+        if (stopped_at != kNoPiece) break;
     }
     uint32_t tail = 0;
-    if (s.cnt >= p.min_hits) {                                                                       // KGJ:511-513
+    if (stopped_at != kNoPiece) {
+        // the next piece's first record lies behind a gap: what the gap rule does there (KGJ:477-484), no carry
+        uint32_t bits = 0;
+        if (s.cnt > 0) {
+            bits = KG_EV_RESET_BEFORE;
+            if (s.cnt >= p.min_hits) {
+                uint64_t tail_votes = 0;
+                if (process_set(hits, acc, vote, begin, p, s, pv, ppv, tail_votes, c, calls, false) & 1u) bits |= KG_EV_CALL_BEFORE;
+                if ((tail_votes >> lane) & 1ull) vote[pv.base + lane] = 1;
+            }
+        }
+        if (lane == 0) before_ev[stopped_at >> pshift] = (uint8_t)bits;
+    } else if (s.cnt >= p.min_hits) {                                                                // KGJ:511-513
         uint64_t tail_votes = 0;                     // voters in the last chunk, whose bytes are already stored
         tail = process_set(hits, acc, vote, begin, p, s, pv, ppv, tail_votes, c, calls, true) & 1u;
         if ((tail_votes >> lane) & 1ull) vote[pv.base + lane] = 1;
     }
-    if (lane == 0) { call_cnt[c] = s.ncalls; tail_ev[c] = (uint8_t)tail; }
+    *tail_out = tail;
+    *reached_end = stopped_at == kNoPiece;
+    return s.ncalls;
+}
+
+// One wave per unit.  Waves [0, n_cwaves): first pieces, per_wave consecutive containers per wave (1 for contigs; more
+// when there are millions of short containers -- reads -- where a wave per container would cost more than the work).
+// Waves behind them: the piece that starts in block u = wave - n_cwaves, if any.  call_cnt[] (the containers' CALL
+// totals) is zeroed by the caller; first_cnt[c] / piece_cnt[u] = the CALLs of a container's first piece / of block u's.
+__global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restrict__ hits, const int64_t *__restrict__ chs,
+                                                         uint32_t n_cont, AggParams p, uint8_t *acc, uint8_t *vote, uint8_t *tail_ev,
+                                                         uint32_t *call_cnt, uint32_t *first_cnt, kg_call *staged /* [n_hits / minHits + 1] */,
+                                                         uint32_t per_wave, uint32_t n_cwaves, const uint32_t *__restrict__ piece_start,
+                                                         uint32_t pshift, uint32_t n_pblocks, uint32_t *piece_cnt, uint8_t *before_ev)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (w >= n_cwaves) {
+        const uint32_t u = w - n_cwaves;
+        if (u >= n_pblocks) return;
+        const uint32_t begin = piece_start[u];
+        if (begin == kNoPiece) return;
+        const uint32_t c = hits[begin].container;
+        const uint32_t end = (uint32_t)chs[c + 1];
+        uint32_t tail;
+        bool reached_end;
+        const uint32_t ncalls = walk_unit(hits, p, acc, vote, begin, end, c, staged + begin / (uint32_t)p.min_hits, piece_start, pshift,
+                                          before_ev, &tail, &reached_end);
+        if (lane == 0) {
+            piece_cnt[u] = ncalls;
+            if (ncalls) atomicAdd(&call_cnt[c], ncalls);
+            if (reached_end) tail_ev[c] = (uint8_t)tail;
+        }
+        return;
+    }
+    const uint32_t c_first = w * per_wave;
+    // The wave's containers' extents in one coalesced load (per_wave <= 64).  Containers with fewer than two hits need
+    // no machine (minHits >= 2: no CALL; a single hit is simply accepted, KGJ:486-497): lanes settle them directly and
+    // the sequential part below visits only the others.
+    uint32_t my_begin = 0, my_end = 0;
+    const bool mine = (uint32_t)lane < per_wave && c_first + (uint32_t)lane < n_cont;
+    if (mine) { my_begin = (uint32_t)chs[c_first + lane]; my_end = (uint32_t)chs[c_first + lane + 1]; }
+    if (mine && my_end - my_begin < 2) {
+        first_cnt[c_first + lane] = 0;
+        tail_ev[c_first + lane] = 0;
+        if (my_end != my_begin) { acc[my_begin] = (uint8_t)KG_EV_ACCEPTED; vote[my_begin] = 0; }
+    }
+    uint64_t todo = __ballot(mine && my_end - my_begin >= 2);
+    while (todo) {
+        const int ci = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t c = c_first + (uint32_t)ci;
+        const uint32_t begin = (uint32_t)rl((int32_t)my_begin, ci), end = (uint32_t)rl((int32_t)my_end, ci);
+        uint32_t tail;
+        bool reached_end;
+        const uint32_t ncalls = walk_unit(hits, p, acc, vote, begin, end, c, staged + begin / (uint32_t)p.min_hits, piece_start, pshift,
+                                          before_ev, &tail, &reached_end);
+        if (lane == 0) {
+            first_cnt[c] = ncalls;
+            if (ncalls) atomicAdd(&call_cnt[c], ncalls);
+            if (reached_end) tail_ev[c] = (uint8_t)tail;
+        }
     }
 }
 
-// staged CALL records -> calls[] in emission order: container c's records sit at staged[chs[c] / minHits ...] and go to
-// calls[call_off[c] ...].  W lanes per container (W = 64: few containers with many CALLs; W = 1: millions of reads).
+// staged CALL records -> calls[] in emission order: the records of container c's first piece sit at
+// staged[chs[c] / minHits ...], those of a later piece at staged[its first record / minHits ...]; all go to
+// calls[call_off[c] ...], piece after piece.  W lanes per container (W = 64: few containers with many CALLs; W = 1: millions
+// of reads).
 template <int W>
 __global__ __launch_bounds__(256) void compact_calls_kernel(const kg_call *__restrict__ staged, const int64_t *__restrict__ chs,
-                                                            const uint32_t *__restrict__ call_cnt, const uint32_t *__restrict__ call_off,
-                                                            uint32_t n_cont, uint32_t min_hits, kg_call *__restrict__ calls)
+                                                            const uint32_t *__restrict__ first_cnt, const uint32_t *__restrict__ call_off,
+                                                            uint32_t n_cont, uint32_t min_hits, kg_call *__restrict__ calls,
+                                                            const uint32_t *__restrict__ piece_start, const uint32_t *__restrict__ piece_cnt,
+                                                            uint32_t pshift)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t c = t / W;
     if (c >= n_cont) return;
-    const uint32_t n = call_cnt[c];
-    const kg_call *src = staged + (uint32_t)chs[c] / min_hits;
+    const uint32_t begin = (uint32_t)chs[c], end = (uint32_t)chs[c + 1];
     kg_call *dst = calls + call_off[c];
-    for (uint32_t k = (uint32_t)(t % W); k < n; k += W) dst[k] = src[k];
+    {
+        const uint32_t n = first_cnt[c];
+        const kg_call *src = staged + begin / min_hits;
+        for (uint32_t k = (uint32_t)(t % W); k < n; k += W) dst[k] = src[k];
+        dst += n;
+    }
+    if (piece_start && end > begin) {
+        if (W == 64) {
+            // a chromosome's container has hundreds of pieces with a few CALLs each: a lane per piece, their places by a wave scan
+            const int lane = threadIdx.x & 63;
+            const uint32_t last = (end - 1u) >> pshift;
+            for (uint32_t u0 = begin >> pshift; u0 <= last; u0 += 64) {
+                const uint32_t u = u0 + (uint32_t)lane;
+                const uint32_t ps = u <= last ? piece_start[u] : kNoPiece;
+                const bool mine = ps > begin && ps < end;
+                const uint32_t n = mine ? piece_cnt[u] : 0u;
+                uint32_t incl = n;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+                    if (lane >= off) incl += v;
+                }
+                const kg_call *src = staged + (mine ? ps / min_hits : 0u);
+                for (uint32_t k = 0; k < n; k++) dst[incl - n + k] = src[k];
+                dst += (uint32_t)__shfl((int)incl, 63);
+            }
+        } else {
+            for (uint32_t u = begin >> pshift; u <= (end - 1u) >> pshift; u++) {
+                const uint32_t ps = piece_start[u];
+                if (ps <= begin || ps >= end) continue;
+                const uint32_t n = piece_cnt[u];
+                const kg_call *src = staged + ps / min_hits;
+                for (uint32_t k = (uint32_t)(t % W); k < n; k += W) dst[k] = src[k];
+                dst += n;
+            }
+        }
+    }
 }
 
 // ccs[c] = call_off[c] widened, plus sentinel
@@ -359,77 +534,101 @@ __global__ void call_starts_kernel(const uint32_t *call_off, uint64_t n_cont, co
     ccs[c] = c == n_cont ? (int64_t)*total : (int64_t)call_off[c];
 }
 
-// OTU vote (KGJ:413-439), one wave per sequence: the records whose vote counted towards a CALL (vote[], left by
-// calls_wave_kernel) are replayed in record order -- the reference's order: CALLs of a container are emitted with
-// ascending, disjoint voter ranges, containers in order -- against the 5-entry buffer that persists across the
-// sequence's containers (KGJ:528, 540).  The buffer lives in wave-uniform registers; the records are streamed in
-// 64-record chunks, the next chunk requested before the current one is replayed.
-__global__ __launch_bounds__(256) void otu_wave_kernel(const kg_hit *__restrict__ hits, const uint8_t *__restrict__ vote,
-                                                       const int64_t *__restrict__ chs, const uint32_t *__restrict__ call_cnt,
-                                                       uint32_t n_seqs, uint32_t per, kg_otu *otu, uint32_t per_wave,
+// OTU vote (KGJ:413-439).  The records whose vote counted towards a CALL (vote[], left by calls_wave_kernel) are replayed
+// in record order -- the reference's order: CALLs of a container are emitted with ascending, disjoint voter ranges,
+// containers in order -- against the 5-entry buffer that persists across the sequence's containers (KGJ:528, 540).  The
+// replay is sequential per sequence, but only over the voters: two small parallel kernels pull the voters' otuIndex values
+// out of hits[] into one dense list first (count per 64-record chunk, prefix sum, scatter); a wave that walked all of a
+// chromosome's 10^5-10^6 records to find them took 2-6 ms (tools/ecoli_time.py).
+__global__ __launch_bounds__(256) void voter_count_kernel(const uint8_t *__restrict__ vote, uint32_t n_hits, uint32_t *__restrict__ cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t m = __ballot(i < n_hits && vote[i] != 0);
+    if ((threadIdx.x & 63) == 0 && (i & ~63u) < n_hits) cnt[i >> 6] = (uint32_t)__popcll(m);
+}
+
+__global__ __launch_bounds__(256) void voter_scatter_kernel(const kg_hit *__restrict__ hits, const uint8_t *__restrict__ vote,
+                                                            uint32_t n_hits, const uint32_t *__restrict__ voff, int32_t *__restrict__ vlist)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool v = i < n_hits && vote[i] != 0;
+    const uint64_t m = __ballot(v);
+    if (v) vlist[voff[i >> 6] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = hits[i].oI;
+}
+
+// one wave per sequence (per_wave consecutive sequences per wave when there are millions of short ones)
+__global__ __launch_bounds__(256) void otu_wave_kernel(const int32_t *__restrict__ vlist, const uint32_t *__restrict__ voff,
+                                                       const uint8_t *__restrict__ vote, const int64_t *__restrict__ chs,
+                                                       uint32_t n_hits, uint32_t n_seqs, uint32_t per, kg_otu *otu, uint32_t per_wave,
                                                        const kg_otu *__restrict__ otu_init)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t s_first = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6))) * per_wave;
+    // index in vlist[] of the first voter at or behind record i
+    auto voter_index = [&](uint32_t i) -> uint32_t {
+        const uint32_t c0 = i & ~63u;
+        const uint64_t m = __ballot(c0 + (uint32_t)lane < n_hits && c0 + (uint32_t)lane < i && vote[c0 + lane] != 0);
+        return (c0 < n_hits ? voff[c0 >> 6] : voff[(n_hits + 63u) >> 6]) + (uint32_t)__popcll(m);
+    };
     for (uint32_t s = s_first; s < s_first + per_wave && s < n_seqs; s++) {
-    int32_t n = 0;
-    int32_t cnt[KG_OI_BUFSZ] = {0, 0, 0, 0, 0}, oi[KG_OI_BUFSZ] = {0, 0, 0, 0, 0};
-    if (otu_init) {                                                     // the caller's oICounts (kg_aggregate_hits)
-        const kg_otu r0 = otu_init[s];
-        n = min(max(r0.n, 0), KG_OI_BUFSZ);
+        int32_t n = 0;
+        int32_t cnt[KG_OI_BUFSZ] = {0, 0, 0, 0, 0}, oi[KG_OI_BUFSZ] = {0, 0, 0, 0, 0};
+        if (otu_init) {                                                     // the caller's oICounts (kg_aggregate_hits)
+            const kg_otu r0 = otu_init[s];
+            n = min(max(r0.n, 0), KG_OI_BUFSZ);
 #pragma unroll
-        for (int k = 0; k < KG_OI_BUFSZ; k++) { cnt[k] = r0.count[k]; oi[k] = r0.oI[k]; }
-    }
-    for (uint32_t f = 0; f < per; f++) {
-    const uint64_t c = (uint64_t)s * per + f;
-    if (call_cnt[c] == 0) continue;                                     // no CALL, no voters (metagenome contigs: almost all)
-    const uint32_t begin = (uint32_t)chs[c], end = (uint32_t)chs[c + 1];
-    bool n_vote = false;
-    int32_t n_o = 0;
-    if (begin + (uint32_t)lane < end) { n_vote = vote[begin + lane] != 0; n_o = hits[begin + lane].oI; }
-    for (uint32_t b = begin; b < end; b += 64) {
-        const bool v = n_vote;
-        const int32_t o = n_o;
-        n_vote = false; n_o = 0;
-        if (b + 64u + (uint32_t)lane < end) { n_vote = vote[b + 64u + lane] != 0; n_o = hits[b + 64u + lane].oI; }
-        uint64_t m = __ballot(v);
-        while (m) {
-            const int k = __builtin_ctzll(m);
-            m &= m - 1;
-            const int32_t ok = rl(o, k);
-            int j = n;                                              // KGJ:416-417 linear search
+            for (int k = 0; k < KG_OI_BUFSZ; k++) { cnt[k] = r0.count[k]; oi[k] = r0.oI[k]; }
+        }
+        const uint32_t vb = voter_index((uint32_t)chs[(uint64_t)s * per]), ve = voter_index((uint32_t)chs[(uint64_t)(s + 1) * per]);
+        int32_t n_o = vb + (uint32_t)lane < ve ? vlist[vb + lane] : 0;
+        for (uint32_t b = vb; b < ve; b += 64) {
+            const int32_t o = n_o;
+            n_o = b + 64u + (uint32_t)lane < ve ? vlist[b + 64u + lane] : 0;     // the next chunk, before this one is replayed
+            const int nv = (int)min(64u, ve - b);
+            // Consecutive voters with the same otuIndex (a genome's hits mostly name its own OTU) are replayed as one step
+            // of their count: r single steps = add r, then one pass of the bubble (an entry only ever moves forward, past the
+            // neighbours whose count does not exceed its own, and its count only grows -- the same neighbours either way;
+            // a new entry likewise: inserted with 1 and raised r - 1 times = inserted with r).
+            const int32_t before = __shfl_up(o, 1);
+            uint64_t heads = __ballot(lane < nv && (lane == 0 || o != before));
+            while (heads) {
+                const int k = __builtin_ctzll(heads);
+                heads &= heads - 1;
+                const int32_t r = (heads ? __builtin_ctzll(heads) : nv) - k;
+                const int32_t ok = rl(o, k);
+                int j = n;                                              // KGJ:416-417 linear search
 #pragma unroll
-            for (int t = KG_OI_BUFSZ - 1; t >= 0; t--)
-                if (t < n && oi[t] == ok) j = t;
-            if (j == n) {                                           // KGJ:418-427
-                if (n == KG_OI_BUFSZ) j--; else n++;
+                for (int t = KG_OI_BUFSZ - 1; t >= 0; t--)
+                    if (t < n && oi[t] == ok) j = t;
+                if (j == n) {                                           // KGJ:418-427
+                    if (n == KG_OI_BUFSZ) j--; else n++;
 #pragma unroll
-                for (int t = 0; t < KG_OI_BUFSZ; t++)
-                    if (t == j) { oi[t] = ok; cnt[t] = 1; }
-            } else {
+                    for (int t = 0; t < KG_OI_BUFSZ; t++)
+                        if (t == j) { oi[t] = ok; cnt[t] = r; }
+                } else {
 #pragma unroll
-                for (int t = 0; t < KG_OI_BUFSZ; t++)
-                    if (t == j) cnt[t]++;
-            }
+                    for (int t = 0; t < KG_OI_BUFSZ; t++)
+                        if (t == j) cnt[t] += r;
+                }
 #pragma unroll
-            for (int t = KG_OI_BUFSZ - 1; t >= 1; t--) {            // KGJ:432-437 bubble toward the front
-                if (j == t && cnt[t - 1] <= cnt[t]) {
-                    int32_t tc = cnt[t - 1], to = oi[t - 1];
-                    cnt[t - 1] = cnt[t]; oi[t - 1] = oi[t];
-                    cnt[t] = tc; oi[t] = to;
-                    j = t - 1;
+                for (int t = KG_OI_BUFSZ - 1; t >= 1; t--) {            // KGJ:432-437 bubble toward the front
+                    if (j == t && cnt[t - 1] <= cnt[t]) {
+                        int32_t tc = cnt[t - 1], to = oi[t - 1];
+                        cnt[t - 1] = cnt[t]; oi[t - 1] = oi[t];
+                        cnt[t] = tc; oi[t] = to;
+                        j = t - 1;
+                    }
                 }
             }
         }
-    }
-    }
-    if (lane == 0) {
-        kg_otu r;
-        r.n = n;
+        if (lane == 0) {
+            kg_otu r;
+            r.n = n;
 #pragma unroll
-        for (int k = 0; k < KG_OI_BUFSZ; k++) { r.count[k] = k < n ? cnt[k] : 0; r.oI[k] = k < n ? oi[k] : 0; }
-        otu[s] = r;
-    }
+            for (int k = 0; k < KG_OI_BUFSZ; k++) { r.count[k] = k < n ? cnt[k] : 0; r.oI[k] = k < n ? oi[k] : 0; }
+            otu[s] = r;
+        }
     }
 }
 

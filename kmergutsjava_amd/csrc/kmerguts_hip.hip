@@ -595,44 +595,102 @@ struct Scratch {
 // Everything is enqueued on t->stream and nothing is waited for: calls[] is allocated for the most CALLs n_hits records can
 // make (n_hits / minHits), so the host does not need the CALL total before the records are compacted; the total arrives in
 // t->h_pin[kPinCalls] once the caller has synchronised the stream.
-constexpr int kPinCalls = 88;
+constexpr int kPinCalls = 88, kPinPieces = 89;
 int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc, int64_t n_seqs, uint64_t n_cont, uint64_t n_hits,
-                    uint32_t PER, uint64_t *d_partial, uint64_t *d_totals, const kg_otu *d_otu_init)
+                    uint32_t PER, uint64_t *d_partial, uint64_t *d_totals, const kg_otu *d_otu_init, bool allow_pieces)
 {
     int rc;
     {
         kg::AggParams ap;
         ap.min_hits = p->min_hits; ap.min_weighted_hits = p->min_weighted_hits;
         ap.max_gap = p->max_gap; ap.order_constraint = p->order_constraint ? 1 : 0;
-        uint32_t *d_ccnt = nullptr, *d_coff = nullptr;
+        uint32_t *d_ccnt = nullptr, *d_coff = nullptr, *d_first = nullptr;
         kg_call *d_staged = nullptr;
         uint8_t *d_vote = nullptr;
         if ((rc = dalloc(t, (void **)&res->d_ev, n_hits))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_tail_ev, n_cont))) return rc;
         uint8_t *d_acc = res->d_ev;
         if ((rc = sc.get(&d_ccnt, n_cont))) return rc;
+        if ((rc = sc.get(&d_first, n_cont))) return rc;
         if ((rc = sc.get(&d_coff, n_cont))) return rc;
         if ((rc = sc.get(&d_vote, n_hits))) return rc;
-        // a hit votes for at most one CALL and a CALL needs >= minHits voters: container c's CALLs fit in
-        // [chs[c] / minHits, chs[c + 1] / minHits) of the staging array (kg_aggregate.hpp)
+        // a hit votes for at most one CALL and a CALL needs >= minHits voters: the CALLs of a unit (a container, or a piece of a
+        // long one) that starts at record b and ends before record e fit in [b / minHits, e / minHits) of the staging array
         if ((rc = sc.get(&d_staged, (size_t)(n_hits / (uint64_t)p->min_hits + 1)))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_ccs, (n_cont + 1) * 8))) return rc;
         if ((rc = dalloc(t, (void **)&res->d_otu, (size_t)(n_seqs ? n_seqs : 1) * sizeof(kg_otu)))) return rc;
-        // one wave per container; several consecutive containers per wave when there are millions of them (short reads)
+        // Long containers in pieces that start behind a gap > maxGap (kg_aggregate.hpp): exact when no -O (with it the gap
+        // is measured from the last ACCEPTED record) and position + maxGap cannot wrap (the caller vouches for positions
+        // < 2^30).  KG_AGG_BLOCK_SHIFT: log2 of the records per block (at most one piece start per block; tests lower it).
+        const uint32_t pshift = std::min(20u, std::max(6u, env_u32("KG_AGG_BLOCK_SHIFT", 9u)));
+        const bool pieces = allow_pieces && !p->order_constraint && p->max_gap >= 0 && p->max_gap < (1 << 30) && n_cont &&
+                            n_hits > (2ull << pshift) && env_u32("KG_AGG_PIECES", 1u) != 0;
+        const uint32_t n_pblocks = pieces ? (uint32_t)((n_hits + (1ull << pshift) - 1) >> pshift) : 0u;
+        uint32_t *d_pstart = nullptr, *d_pcnt = nullptr;
+        uint8_t *d_before = nullptr;
+        t->h_pin[kPinCalls] = 0;
+        t->h_pin[kPinPieces] = 0;
+        {   // clears: the containers' CALL totals (units add to them), the pieces' counts and hand-over bytes
+            kg::ClearList cl;
+            cl.n = 0;
+            for (int k = 0; k < 8; k++) { cl.p[k] = nullptr; cl.words[k] = 0; }
+            if (n_cont) { cl.p[cl.n] = d_ccnt; cl.words[cl.n++] = n_cont; }
+            if (pieces) {
+                if ((rc = sc.get(&d_pstart, (size_t)n_pblocks + 1))) return rc;
+                if ((rc = sc.get(&d_pcnt, (size_t)n_pblocks + 1))) return rc;
+                if ((rc = sc.get(&d_before, ((size_t)n_pblocks + 4) & ~(size_t)3))) return rc;
+                cl.p[cl.n] = d_pcnt; cl.words[cl.n++] = (uint64_t)n_pblocks + 1;
+                cl.p[cl.n] = reinterpret_cast<uint32_t *>(d_before); cl.words[cl.n++] = ((uint64_t)n_pblocks + 4) / 4;
+            }
+            if (cl.n) {
+                uint64_t most = 0;
+                for (int k = 0; k < cl.n; k++) most = std::max(most, cl.words[k]);
+                hipLaunchKernelGGL(kg::clear_many_kernel, dim3((uint32_t)std::min<uint64_t>(1024, most / 1024 + 1)), dim3(256), 0, t->stream, cl);
+            }
+        }
+        if (pieces)
+            hipLaunchKernelGGL(kg::piece_starts_kernel, dim3((n_pblocks + 3) / 4), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
+                               (uint32_t)n_hits, pshift, ap.max_gap, d_pstart, n_pblocks);
+        // one wave per unit: the containers' first pieces (several consecutive containers per wave when there are millions of
+        // them: short reads), then one per block of hits[] that a later piece may start in
         const uint32_t cpw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, n_cont / (1u << 17)));
-        uint32_t cgrid = (uint32_t)(((n_cont + cpw - 1) / cpw + 3) / 4);
+        const uint32_t n_cwaves = (uint32_t)((n_cont + cpw - 1) / cpw);
         if (n_cont) {
-            hipLaunchKernelGGL(kg::calls_wave_kernel, dim3(cgrid), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
-                               (uint32_t)n_cont, ap, d_acc, d_vote, res->d_tail_ev, d_ccnt, d_staged, cpw);
+            hipLaunchKernelGGL(kg::calls_wave_kernel, dim3((n_cwaves + n_pblocks + 3) / 4), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
+                               (uint32_t)n_cont, ap, d_acc, d_vote, res->d_tail_ev, d_ccnt, d_first, d_staged, cpw, n_cwaves, d_pstart,
+                               pshift, n_pblocks, d_pcnt, d_before);
+            if (pieces)
+                hipLaunchKernelGGL(kg::merge_before_kernel, dim3((n_pblocks + 255) / 256), dim3(256), 0, t->stream, d_pstart, d_before,
+                                   n_pblocks, res->d_ev, (unsigned long long *)(d_totals + 6));
             HIP_TRY(hipGetLastError());
         }
         if ((rc = prefix_sum(t, d_ccnt, n_cont, d_coff, d_partial, d_totals + 4))) return rc;
-        t->h_pin[kPinCalls] = 0;
         if (n_cont) HIP_TRY(hipMemcpyAsync(t->h_pin + kPinCalls, d_totals + 4, 8, hipMemcpyDeviceToHost, t->stream));
+        if (pieces) HIP_TRY(hipMemcpyAsync(t->h_pin + kPinPieces, d_totals + 6, 8, hipMemcpyDeviceToHost, t->stream));
         if (n_seqs) {
+            // the voters of all CALLs as one dense list of otuIndex values in record order, then the replay per sequence
+            const uint32_t n_vchunks = (uint32_t)((n_hits + 63) / 64);
+            uint32_t *d_vcnt = nullptr, *d_voff = nullptr;
+            int32_t *d_vlist = nullptr;
+            uint64_t *d_vpartial = nullptr;
+            if ((rc = sc.get(&d_vcnt, (size_t)n_vchunks + 1))) return rc;
+            if ((rc = sc.get(&d_voff, (size_t)n_vchunks + 1))) return rc;
+            if ((rc = sc.get(&d_vlist, (size_t)n_hits + 1))) return rc;
+            if ((rc = sc.get(&d_vpartial, (size_t)((n_vchunks + 1) / kg::kScanChunk + 2)))) return rc;
+            if (n_hits) {
+                const uint32_t vgrid = (uint32_t)((n_hits + 255) / 256);
+                hipLaunchKernelGGL(kg::voter_count_kernel, dim3(vgrid), dim3(256), 0, t->stream, d_vote, (uint32_t)n_hits, d_vcnt);
+                // (n_vchunks + 1 items: the entry behind the last chunk is the total, read for "behind the last record")
+                HIP_TRY(hipMemsetAsync(d_vcnt + n_vchunks, 0, 4, t->stream));
+                if ((rc = prefix_sum(t, d_vcnt, (uint64_t)n_vchunks + 1, d_voff, d_vpartial, d_totals + 7))) return rc;
+                hipLaunchKernelGGL(kg::voter_scatter_kernel, dim3(vgrid), dim3(256), 0, t->stream, res->d_hits, d_vote, (uint32_t)n_hits, d_voff,
+                                   d_vlist);
+            } else {
+                HIP_TRY(hipMemsetAsync(d_voff, 0, 4, t->stream));
+            }
             const uint32_t spw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (uint64_t)n_seqs / (1u << 17)));
             hipLaunchKernelGGL(kg::otu_wave_kernel, dim3((uint32_t)((((uint64_t)n_seqs + spw - 1) / spw + 3) / 4)), dim3(256), 0, t->stream,
-                               res->d_hits, d_vote, res->d_chs, d_ccnt, (uint32_t)n_seqs, PER, res->d_otu, spw, d_otu_init);
+                               d_vlist, d_voff, d_vote, res->d_chs, (uint32_t)n_hits, (uint32_t)n_seqs, PER, res->d_otu, spw, d_otu_init);
         }
         hipLaunchKernelGGL(kg::call_starts_kernel, dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream, d_coff,
                            n_cont, d_totals + 4, res->d_ccs);
@@ -640,10 +698,12 @@ int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc
         if (n_cont) {
             if (n_cont < (1u << 17))
                 hipLaunchKernelGGL((kg::compact_calls_kernel<64>), dim3((uint32_t)((n_cont * 64 + 255) / 256)), dim3(256), 0, t->stream,
-                                   d_staged, res->d_chs, d_ccnt, d_coff, (uint32_t)n_cont, (uint32_t)p->min_hits, res->d_calls);
+                                   d_staged, res->d_chs, d_first, d_coff, (uint32_t)n_cont, (uint32_t)p->min_hits, res->d_calls,
+                                   d_pstart, d_pcnt, pshift);
             else
                 hipLaunchKernelGGL((kg::compact_calls_kernel<1>), dim3((uint32_t)((n_cont + 255) / 256)), dim3(256), 0, t->stream,
-                                   d_staged, res->d_chs, d_ccnt, d_coff, (uint32_t)n_cont, (uint32_t)p->min_hits, res->d_calls);
+                                   d_staged, res->d_chs, d_first, d_coff, (uint32_t)n_cont, (uint32_t)p->min_hits, res->d_calls,
+                                   d_pstart, d_pcnt, pshift);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -1089,10 +1149,13 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
     // ---- aggregation: CALL records and OTU votes ----
     const bool aggregate = !(p->flags & KG_F_SKIP_AGGREGATE);
     if (aggregate)
-        if ((rc = aggregate_stage(t, p, res, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, nullptr))) return rc;
+        if ((rc = aggregate_stage(t, p, res, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, nullptr,
+                                  offsets[n_seqs] - offsets[0] < (1ll << 30) /* record positions < 2^30 */)))
+            return rc;
     HIP_TRY(hipEventRecord(t->ev[4], t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     st.n_calls = aggregate ? (int64_t)t->h_pin[kPinCalls] : 0;
+    st.agg_pieces = aggregate ? (int32_t)std::min<uint64_t>(t->h_pin[kPinPieces], 0x7FFFFFFF) : 0;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, t->ev[1], t->ev[2])); st.ms_scan = ms;
     HIP_TRY(hipEventElapsedTime(&ms, t->ev[2], t->ev[3])); st.ms_order = ms;
@@ -1212,7 +1275,8 @@ int kg_aggregate_hits(int device, const kg_params *p, const kg_hit *hits, const 
         if (n_hits) HIP_TRY(hipMemcpyAsync(r->d_hits, hits, n_hits * sizeof(kg_hit), hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(r->d_chs, container_hit_start, (n_cont + 1) * 8, hipMemcpyHostToDevice, t->stream));
         if (d_init) HIP_TRY(hipMemcpyAsync(d_init, otu_init, (size_t)n_seqs * sizeof(kg_otu), hipMemcpyHostToDevice, t->stream));
-        if ((rc2 = aggregate_stage(t, p, r, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, d_init))) return rc2;
+        // (caller-supplied records: positions are whatever the caller says, so long containers stay in one piece)
+        if ((rc2 = aggregate_stage(t, p, r, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, d_init, false))) return rc2;
         HIP_TRY(hipStreamSynchronize(t->stream));
         r->st.n_seqs = n_seqs; r->st.n_containers = (int64_t)n_cont; r->st.n_hits = (int64_t)n_hits;
         r->st.n_calls = (int64_t)t->h_pin[kPinCalls];

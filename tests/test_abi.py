@@ -30,7 +30,7 @@ def test_header_symbols_are_exported(native):
 def test_record_layouts_match_header(native):
     assert native.HIT_DTYPE.itemsize == 24 and native.CALL_DTYPE.itemsize == 24 and native.OTU_DTYPE.itemsize == 44
     assert ctypes.sizeof(native.KgParams) == 24
-    assert ctypes.sizeof(native.KgStats) == 10 * 8 + 4 * 4 + 2 * 4 + 3 * 4 + 5 * 4
+    assert ctypes.sizeof(native.KgStats) == 10 * 8 + 4 * 4 + 2 * 4 + 3 * 4 + 7 * 4
 
 
 def test_kg_stats_binding_matches_the_c_struct(native, tmp_path):

@@ -232,6 +232,64 @@ def test_hit_cap_39998(hp, oracle, oc):
         assert ora["calls"]["count"].max() == 39998
 
 
+@pytest.mark.parametrize("shift", [6, 7, 9])
+def test_long_containers_in_pieces(hp, oracle, shift, monkeypatch):
+    """gatherHits of a long container is split between waves at records that lie more than maxGap behind their predecessor
+    (the list restarts there anyway, KGJ:477-484).  A protein of dense runs -- one of them longer than the 39 998 cap, some
+    shorter than minHits, some ending in a pair-rule reset -- separated by stretches without hits, against the oracle, with
+    small blocks (many pieces) and the production block size; the same with the pieces switched off; -O never splits."""
+    from kmergutsjava_amd import synth
+    seq, off, rec, keys = synth.high_density_config(2, 50, 20011, 6000, dna=False)
+    img = _img(rec)
+    rng = np.random.default_rng(5)
+    runs = []
+    for k in range(160):
+        n = int(rng.choice([1, 2, 3, 4, 5, 6, 9, 40, 77, 300, 1500]))
+        runs.append(_single_function_protein(keys, rec, n, fn_pick=int(rng.integers(0, 3)), alt_every=int(rng.choice([0, 0, 3, 5]))))
+        runs.append("X" * int(rng.choice([3, 12, 30, 200])))             # 3: no gap (maxGap 10); the others: a gap
+    runs.insert(40, _single_function_protein(keys, rec, 41000))          # over the cap, pieces start right behind it
+    prot = "".join(runs)
+    short = _single_function_protein(keys, rec, 500, fn_pick=2)
+    sb = (prot + short).encode()
+    off = np.array([0, len(prot), len(prot) + len(short)], dtype=np.int64)
+    monkeypatch.setenv("KG_AGG_BLOCK_SHIFT", str(shift))
+    for oc in (False, True):
+        ora = oracle.run(img, sb, off, aa=True, lookup_mode=1, order_constraint=oc, max_gap=10)
+        with hp.SignatureTable.from_bytes(img) as tab:
+            with tab.scan(sb, off, hp.Params(aa=True, order_constraint=oc, max_gap=10)) as r:
+                assert_same_records(r, ora, "pieces shift=%d oc=%s" % (shift, oc))
+                if oc:
+                    assert r.stats["agg_pieces"] == 0
+                else:
+                    assert r.stats["agg_pieces"] >= (30 if shift < 9 else 5), r.stats["agg_pieces"]
+                    assert len(ora["calls"]) > 50 and ora["calls"]["count"].max() == 39998
+            monkeypatch.setenv("KG_AGG_PIECES", "0")
+            with tab.scan(sb, off, hp.Params(aa=True, order_constraint=oc, max_gap=10)) as r:
+                assert_same_records(r, ora, "one piece per container oc=%s" % oc)
+                assert r.stats["agg_pieces"] == 0
+            monkeypatch.delenv("KG_AGG_PIECES")
+
+
+def test_otu_votes_in_runs(hp, oracle):
+    """The OTU stage replays consecutive voters with the same otuIndex as one step (KGJ:413-439 applied r times = count + r
+    and one bubble pass).  Tables whose signatures name very few OTUs, unevenly, so that the voters come in long runs and
+    the 5-entry buffer overflows and reorders: OTU records against the oracle."""
+    from kmergutsjava_amd import synth
+    for n_otu, skew in ((2, 0.9), (3, 0.6), (9, 0.5), (40, 0.3)):
+        seq, off, rec, keys = synth.high_density_config(12, 400, 40009, 9000, seed=77 + n_otu, dna=True)
+        r_ = rec.numpy()
+        rng = np.random.default_rng(n_otu)
+        oi = np.where(rng.random(len(r_)) < skew, 0, rng.integers(0, n_otu, len(r_))).astype(np.int32)
+        r_[:, 2] = oi                                                      # otuIndex column of the 24-byte records
+        img = _img(rec)
+        sb = seq.numpy().tobytes()
+        for mh in (2, 5):
+            ora = oracle.run(img, sb, off, lookup_mode=1, min_hits=mh, max_gap=60)
+            with hp.SignatureTable.from_bytes(img) as tab, tab.scan(sb, off, hp.Params(min_hits=mh, max_gap=60)) as r:
+                assert_same_records(r, ora, "otu runs n_otu=%d mh=%d" % (n_otu, mh))
+            assert len(ora["calls"]) > 20 and ora["otu"]["n"].max() >= min(n_otu, 2)
+
+
 def test_midsize_persistent_waves(hp, oracle):
     """Enough blocks that every persistent wave walks several of them (grid-stride loop, staging
     chunks handed out across blocks), checked record for record against the oracle."""

@@ -4,7 +4,7 @@ tag=$1; shift
 out=gpurun_out/r02/kstat/$tag; mkdir -p $out
 export TMPDIR=/tmp SW_REPS=${SW_REPS:-3}
 for kv in "$@"; do export "$kv"; done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 tools/one_scan.py > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 ${KSTAT_TOOL:-tools/one_scan.py} > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
 find $out -type f ! -name "*kernel_stats.csv" ! -name run.log -delete
 python3 - $out "$tag" <<'PY'
 import csv,sys,json,glob,os
@@ -17,5 +17,5 @@ for r in rows:
     for k in keys:
         if k in r['Name']: d[k]=round(float(r['AverageNs'])/1e6,3)
 js=[json.loads(l) for l in open(out+'/run.log') if l.startswith('{')]
-print(tag, d, 'scan', [round(j['ms_scan'],2) for j in js][1:], 'chunks', js[0]['part_chunks'])
+print(tag, d, 'scan', [round(j['ms_scan'],2) for j in js][1:], 'chunks', js[0].get('part_chunks'))
 PY
