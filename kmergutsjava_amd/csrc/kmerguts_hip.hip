@@ -730,9 +730,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
     // ---- host: window blocks per sequence (KGJ:912 trip counts) ----
     std::vector<uint32_t> ibase((size_t)n_seqs + 1);
     uint64_t nblocks = 0, windows = 0, residues = 0;
+    int64_t longest = 0;                            // (record positions are below the length of their sequence)
     for (int64_t k = 0; k < n_seqs; k++) {
         int64_t L = offsets[k + 1] - offsets[k];
         if (L < 0) return fail(KG_ERR_ARG, "offsets must be non-decreasing");
+        longest = std::max(longest, L);
         if (L > 0xFFFFFFF0ll) return fail(KG_ERR_LIMIT, "a single sequence longer than 2^32-16 characters");
         ibase[(size_t)k] = (uint32_t)nblocks;
         uint64_t nb;
@@ -1148,10 +1150,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
 
     // ---- aggregation: CALL records and OTU votes ----
     const bool aggregate = !(p->flags & KG_F_SKIP_AGGREGATE);
-    if (aggregate)
-        if ((rc = aggregate_stage(t, p, res, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, nullptr,
-                                  offsets[n_seqs] - offsets[0] < (1ll << 30) /* record positions < 2^30 */)))
-            return rc;
+    if (aggregate && (rc = aggregate_stage(t, p, res, sc, n_seqs, n_cont, n_hits, PER, d_partial, d_totals, nullptr, longest < (1ll << 30))))
+        return rc;
     HIP_TRY(hipEventRecord(t->ev[4], t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     st.n_calls = aggregate ? (int64_t)t->h_pin[kPinCalls] : 0;
