@@ -597,6 +597,7 @@ __global__ __launch_bounds__(256) void otu_wave_kernel(const int32_t *__restrict
                 heads &= heads - 1;
                 const int32_t r = (heads ? __builtin_ctzll(heads) : nv) - k;
                 const int32_t ok = rl(o, k);
+                if (n > 0 && oi[0] == ok) { cnt[0] += r; continue; }    // the leading entry: found at 0, nothing to bubble past
                 int j = n;                                              // KGJ:416-417 linear search
 #pragma unroll
                 for (int t = KG_OI_BUFSZ - 1; t >= 0; t--)
