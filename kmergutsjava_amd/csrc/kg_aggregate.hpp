@@ -1,7 +1,8 @@
 // kg_aggregate.hpp -- gatherHits (KGJ:457-514) + processSetOfHits (KGJ:385-455) on gfx950.
 //
-// One wavefront owns one HitContainer (its position-ordered hit records are contiguous in
-// hits[]).  The reference's state machine is sequential per container; the wave runs it with
+// One wavefront owns one UNIT: a HitContainer (its position-ordered hit records are contiguous in
+// hits[]) or, for long containers, a piece of one that starts behind a gap > maxGap (see walk_unit).
+// The reference's state machine is sequential per container; the wave runs it with
 // wave-uniform (scalar) control flow over 64-record chunks that are loaded coalesced:
 //
 //   * The reference's "hits" list is always the accepted records inside one index range
@@ -16,12 +17,13 @@
 //   * processSetOfHits walks the list in 64-record chunks; the float32 weight sum is added in list
 //     order (KGJ:394) by visiting the voters' lanes in ascending order.
 //
-// One pass.  A container's CALL records go to its own range of a staging array: a hit votes for at most one CALL (after a
-// CALL the list is emptied or cut down to two members that did not vote) and a CALL needs >= minHits voters, so container c
-// makes at most hits_c / minHits CALLs and [chs[c] / minHits, chs[c + 1] / minHits) is room enough; the counts are
-// prefix-summed and compact_calls_kernel moves the records to calls[] in the reference's emission order, no atomics.
-// The pass also marks every record whose vote counted towards a CALL (vote[]): the OTU stage (KGJ:413-439) then is one
-// streaming walk over a sequence's records in order -- voters of successive CALLs have ascending indices.
+// One pass.  A unit's CALL records go to its own range of a staging array: a hit votes for at most one CALL (after a
+// CALL the list is emptied or cut down to two members that did not vote) and a CALL needs >= minHits voters, so a unit over
+// the records [b, e) makes at most (e - b) / minHits CALLs and [b / minHits, e / minHits) is room enough; the containers'
+// counts are prefix-summed and compact_calls_kernel moves the records to calls[] in the reference's emission order.
+// The pass also marks every record whose vote counted towards a CALL (vote[]): the OTU stage (KGJ:413-439) pulls those
+// records' otuIndex values into a dense list and replays them per sequence -- voters of successive CALLs have ascending
+// indices, so record order is the reference's order.
 //
 // The pass leaves one event byte per record (KG_EV_* in kmerguts_hip.h) and one per
 // container: what the machine did at that record (appended it, reset the list before / after it,
