@@ -142,6 +142,33 @@ def test_config3_1gbp_contig_mix_full_table(hp, oracle, full_table, monkeypatch)
             assert rs.hits().tobytes() == o1["hits"].tobytes() == ora["hits"].tobytes()
 
 
+def test_aggregation_in_pieces_equals_one_wave_per_container_at_full_size(hp, full_table, monkeypatch):
+    """Long containers are aggregated in pieces that start behind gaps > maxGap (kg_aggregate.hpp).  At BASELINE size --
+    1 Gbp of contigs up to 1 Mbp -- and for ONE contig of 120 Mbp (six containers of 700 k hits) the CALL, OTU and event
+    records must be the ones of the one-wave-per-container walk (KG_AGG_PIECES=0), byte for byte."""
+    from kmergutsjava_amd import synth
+    dev = torch.device("cuda", 0)
+    tab = full_table["tab"]
+    lens = synth.contig_mix_lengths(1_000_000_000, 301)
+    for what, off in (("1 Gbp contig mix", synth.offsets_of(lens)), ("one contig of 120 Mbp", np.array([0, 120_000_000], dtype=np.int64))):
+        seq = synth.random_dna(int(off[-1]), 302, dev)
+        torch.cuda.synchronize()
+        for mh, gap in ((5, 200), (2, 40)):
+            monkeypatch.delenv("KG_AGG_PIECES", raising=False)
+            with tab.scan(None, off, hp.Params(min_hits=mh, max_gap=gap), device_ptr=seq.data_ptr()) as a:
+                assert a.stats["agg_pieces"] > 1000, (what, a.stats["agg_pieces"])
+                monkeypatch.setenv("KG_AGG_PIECES", "0")
+                with tab.scan(None, off, hp.Params(min_hits=mh, max_gap=gap), device_ptr=seq.data_ptr()) as b:
+                    assert b.stats["agg_pieces"] == 0
+                    _same_on_device(a, b, what + " pieces vs none")
+                    assert np.array_equal(a.hit_events(), b.hit_events()), what + ": hit events"
+                    assert np.array_equal(a.container_tail_events(), b.container_tail_events()), what + ": tail events"
+                    if mh == 2:
+                        assert a.stats["n_calls"] > 1000, (what, a.stats["n_calls"])
+        del seq
+        torch.cuda.empty_cache()
+
+
 def test_config2_100mbp_uniform_full_table(hp, oracle, full_table, monkeypatch):
     """BASELINE config 2: 1000 x 100 kbp uniform DNA vs the full table (partitioned by default, one or two chunks)."""
     from kmergutsjava_amd import synth
