@@ -213,6 +213,36 @@ def test_config5_high_density_full_size(hp, oracle, dna, monkeypatch):
                 _same_on_device(ra, rb, "config 5 dna=%s, the two strategies" % dna)
 
 
+def test_table_with_more_than_2_31_slots(hp, oracle):
+    """numSigs >= 2^31: slots and k-mer quotients no longer fit the 32-bit arithmetic of the partitioned strategy
+    (kg::split_fast), so the scan runs the direct kernel with 64-bit slot arithmetic (kg::split_value) -- against a 51.5 GB
+    table, records byte-identical to the oracle's (direct-probe mode), counters included."""
+    from kmergutsjava_amd import synth
+    from helpers import assert_same_records
+    dev = torch.device("cuda", 0)
+    n = (1 << 31) + 11
+    rec, placed, keys = synth.random_table(n, 0.3, 909, dev)
+    del keys
+    torch.cuda.synchronize()
+    lens = synth.contig_mix_lengths(20_000_000, 77)
+    off = synth.offsets_of(lens)
+    seq = synth.random_dna(int(off[-1]), 78, dev)
+    torch.cuda.synchronize()
+    host = torch.empty(24 + n * 24, dtype=torch.uint8)
+    host[:24] = torch.frombuffer(bytearray(struct.pack("<qqq", n, 24, 1)), dtype=torch.uint8)
+    host[24:].view(torch.int32).view(n, 6).copy_(rec)
+    ora = oracle.run(host.numpy(), seq.cpu().numpy(), off, lookup_mode=1)
+    assert len(ora["hits"]) > 100_000 and int(ora["hits"]["container"].max()) > 100
+    with hp.SignatureTable.from_device_ptr(rec.data_ptr(), n, 0, keepalive=rec) as tab:
+        assert tab.info()["numSigs"] == n and tab.info()["occupied"] == placed
+        with tab.scan(None, off, hp.Params(counters=True), device_ptr=seq.data_ptr()) as r:
+            assert r.stats["partitioned"] == 0
+            assert_same_records(r, ora, "2^31 + 11 slots")
+            assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
+    del host, rec
+    torch.cuda.empty_cache()
+
+
 def test_sharded_scans_restored_on_the_device_equal_the_unsharded_scan(hp):
     """The exchange step of the multi-GPU layer without a process group: the batch is cut into three shards of whole
     contigs (distributed.shard_sequences), every shard is scanned on this GPU, the library's own HBM buffers are wrapped
