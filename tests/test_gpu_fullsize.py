@@ -243,6 +243,33 @@ def test_table_with_more_than_2_31_slots(hp, oracle):
     torch.cuda.empty_cache()
 
 
+def test_largest_batch_and_the_limit_behind_it(hp, oracle, full_table):
+    """A 2 Gbp batch (3.99e9 of the 2^32 - 256 windows one call takes; more than the 2^23 window blocks of the partitioned
+    strategy, so the direct kernel runs): properties of the whole result and the oracle on contigs from its start, middle
+    and end.  One more contig pushes the batch over the limit: KG_ERR_LIMIT before anything is touched."""
+    from kmergutsjava_amd import synth, _native
+    dev = torch.device("cuda", 0)
+    tab = full_table["tab"]
+    lens = synth.contig_mix_lengths(2_000_000_000, 401)
+    off = synth.offsets_of(lens)
+    seq = synth.random_dna(int(off[-1]), 402, dev)
+    torch.cuda.synchronize()
+    with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as r:
+        st = r.stats
+        assert st["partitioned"] == 0 and st["fallback"] == 0 and st["windows"] > 3_900_000_000 and st["n_hits"] > 70_000_000, st
+        _whole_result_properties(r, 6)
+        idx = synth.spread_sample(off, groups=3, per_group=12, max_bp_per_group=1_500_000)
+        assert idx[0] < len(lens) // 3 and idx[-1] > len(lens) * 2 // 3
+        _oracle_sample(oracle, full_table["image"](), seq, off, idx, r, "2 Gbp batch")
+    big = np.concatenate([lens, [300_000_000]])          # 2.3 Gbp: 4.6e9 windows
+    off_big = synth.offsets_of(big)
+    with pytest.raises(_native.KmerGutsNativeError) as ei:
+        tab.scan(None, off_big, hp.Params(), device_ptr=seq.data_ptr())     # (refused from the offsets alone)
+    assert ei.value.code == -7
+    del seq
+    torch.cuda.empty_cache()
+
+
 def test_sharded_scans_restored_on_the_device_equal_the_unsharded_scan(hp):
     """The exchange step of the multi-GPU layer without a process group: the batch is cut into three shards of whole
     contigs (distributed.shard_sequences), every shard is scanned on this GPU, the library's own HBM buffers are wrapped
