@@ -270,6 +270,51 @@ def test_largest_batch_and_the_limit_behind_it(hp, oracle, full_table):
     torch.cuda.empty_cache()
 
 
+def test_largest_partitioned_batch_and_protein_at_scale(hp, oracle, full_table, monkeypatch):
+    """The partitioned strategy at its upper end -- 1.55 Gbp, 8.07 M of the 2^23 window blocks it takes, four chunks of
+    390 Mbp -- and in protein mode at scale (300 M residues in 330-residue proteins: one window row per block, no strands):
+    both against the direct kernel on the device, plus the oracle on proteins drawn from every chunk."""
+    from kmergutsjava_amd import synth
+    dev = torch.device("cuda", 0)
+    tab = full_table["tab"]
+    # -- DNA, 1.55 Gbp
+    lens = synth.contig_mix_lengths(1_550_000_000, 501)
+    off = synth.offsets_of(lens)
+    seq = synth.random_dna(int(off[-1]), 502, dev)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("KG_PARTITION", raising=False)
+    with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as rp:
+        assert rp.stats["partitioned"] == 1 and rp.stats["fallback"] == 0 and rp.stats["part_chunks"] == 4, rp.stats
+        assert 8_000_000 < rp.stats["n_blocks"] <= (1 << 23)
+        _whole_result_properties(rp, 6)
+        monkeypatch.setenv("KG_PARTITION", "0")
+        with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as rd:
+            assert rd.stats["partitioned"] == 0
+            _same_on_device(rp, rd, "1.55 Gbp partitioned vs direct")
+    del seq
+    torch.cuda.empty_cache()
+    # -- protein, 300 M residues
+    lens = np.full(300_000_000 // 330, 330, dtype=np.int64)
+    lens[::9] = 1200
+    lens[::31] = 7                                        # too short for a window
+    off = synth.offsets_of(lens)
+    seq = synth.random_protein(int(off[-1]), 503, dev)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("KG_PARTITION", raising=False)
+    with tab.scan(None, off, hp.Params(aa=True, min_hits=2), device_ptr=seq.data_ptr()) as rp:
+        assert rp.stats["partitioned"] == 1 and rp.stats["fallback"] == 0, rp.stats
+        _whole_result_properties(rp, 1)
+        idx = synth.spread_sample(off, groups=max(1, rp.stats["part_chunks"]), per_group=400, max_bp_per_group=400_000)
+        ora = _oracle_sample(oracle, full_table["image"](), seq, off, idx, rp, "protein at scale", aa=True, min_hits=2)
+        assert len(ora["hits"]) > 5_000
+        monkeypatch.setenv("KG_PARTITION", "0")
+        with tab.scan(None, off, hp.Params(aa=True, min_hits=2), device_ptr=seq.data_ptr()) as rd:
+            assert rd.stats["partitioned"] == 0
+            _same_on_device(rp, rd, "300 M residues partitioned vs direct")
+    del seq
+    torch.cuda.empty_cache()
+
+
 def test_sharded_scans_restored_on_the_device_equal_the_unsharded_scan(hp):
     """The exchange step of the multi-GPU layer without a process group: the batch is cut into three shards of whole
     contigs (distributed.shard_sequences), every shard is scanned on this GPU, the library's own HBM buffers are wrapped
