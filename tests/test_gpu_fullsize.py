@@ -186,6 +186,13 @@ def test_config2_100mbp_uniform_full_table(hp, oracle, full_table, monkeypatch):
         with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as rd:
             assert rd.stats["partitioned"] == 0
             _same_on_device(rp, rd, "config 2 partitioned vs direct")
+    # the other parameters of the CLI (-O, -m, -M, -g) at this size: oracle on the same sample
+    monkeypatch.delenv("KG_PARTITION", raising=False)
+    for kw in (dict(order_constraint=True, min_hits=2, max_gap=600), dict(min_hits=3, min_weighted_hits=2, max_gap=50),
+               dict(min_hits=2, max_gap=2_000_000_000)):
+        with tab.scan(None, off, hp.Params(**kw), device_ptr=seq.data_ptr()) as r:
+            assert r.stats["fallback"] == 0 and (r.stats["agg_pieces"] == 0 or not kw.get("order_constraint"))
+            _oracle_sample(oracle, full_table["image"](), seq, off, idx, r, "config 2 %s" % kw, **kw)
 
 
 @pytest.mark.parametrize("dna", [True, False])
