@@ -547,6 +547,7 @@ __global__ __launch_bounds__(256) void voter_count_kernel(const uint8_t *__restr
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t m = __ballot(i < n_hits && vote[i] != 0);
     if ((threadIdx.x & 63) == 0 && (i & ~63u) < n_hits) cnt[i >> 6] = (uint32_t)__popcll(m);
+    if (i == 0) cnt[(n_hits + 63u) >> 6] = 0;              // the item behind the last chunk (its prefix = the total)
 }
 
 __global__ __launch_bounds__(256) void voter_scatter_kernel(const kg_hit *__restrict__ hits, const uint8_t *__restrict__ vote,

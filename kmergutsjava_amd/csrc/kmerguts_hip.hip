@@ -679,9 +679,9 @@ int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc
             if ((rc = sc.get(&d_vpartial, (size_t)((n_vchunks + 1) / kg::kScanChunk + 2)))) return rc;
             if (n_hits) {
                 const uint32_t vgrid = (uint32_t)((n_hits + 255) / 256);
+                // (n_vchunks + 1 items: the kernel zeroes the entry behind the last chunk; its prefix is the total, read for
+                //  "behind the last record")
                 hipLaunchKernelGGL(kg::voter_count_kernel, dim3(vgrid), dim3(256), 0, t->stream, d_vote, (uint32_t)n_hits, d_vcnt);
-                // (n_vchunks + 1 items: the entry behind the last chunk is the total, read for "behind the last record")
-                HIP_TRY(hipMemsetAsync(d_vcnt + n_vchunks, 0, 4, t->stream));
                 if ((rc = prefix_sum(t, d_vcnt, (uint64_t)n_vchunks + 1, d_voff, d_vpartial, d_totals + 7))) return rc;
                 hipLaunchKernelGGL(kg::voter_scatter_kernel, dim3(vgrid), dim3(256), 0, t->stream, res->d_hits, d_vote, (uint32_t)n_hits, d_voff,
                                    d_vlist);
