@@ -9,7 +9,12 @@ KmerGuts signature table.  With N ranks (BASELINE.jso
 1 Gbp contig list is cut into N shards of whole contigs (strong scaling, the default; every rank
 generates only its shard), each rank scans its shard against its own replica of the table, and the
 per-rank CALL / OTU / hit buffers are gathered to rank 0 over RCCL inside the timed region, device
-buffer to device buffer.  --scaling weak gives every rank its own 1 Gbp instead.
+buffer to device buffer (--no-gather-hits leaves the hit records sharded and times only the CALL / OTU
+exchange).  --scaling weak gives every rank its own 1 Gbp instead.
+
+`--gpus N` with N > 1 outside a launcher (no WORLD_SIZE in the environment) starts the N ranks itself
+(`python -m torch.distributed.run`, one process per GPU, 127.0.0.1 rendezvous) BEFORE anything touches
+the GPU and exits with the launcher's code; under a launcher, WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
@@ -51,15 +56,38 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the one --total-bp contig list sharded over the ranks (BASELINE config 4), "
                          "weak = --total-bp per rank")
-    ap.add_argument("--gather-hits", action="store_true",
-                    help="N > 1: gather the hit records too inside the timed steps (default: CALL / OTU records, the report's "
-                         "content; the hit records, which only the -d stream prints, stay sharded in HBM and their gather is "
-                         "exercised and timed in two extra steps after the timed region: 'hits_gather_probe')")
+    ap.add_argument("--gather-hits", dest="gather_hits", action="store_true", default=True,
+                    help="N > 1 (default): the per-rank hit buffers are gathered to rank 0 inside the timed steps, with the "
+                         "CALL / OTU records (BASELINE config 4: 'RCCL-over-xGMI gather of hit buffers')")
+    ap.add_argument("--no-gather-hits", dest="gather_hits", action="store_false",
+                    help="N > 1, secondary mode: only the CALL / OTU records (the report's content) travel inside the timed "
+                         "steps; the hit records, which only the -d stream prints, stay sharded in HBM and their gather is "
+                         "exercised and timed in two extra steps after the timed region ('hits_gather_probe')")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     ap.add_argument("--strategy", choices=["auto", "direct", "partitioned"], default="auto",
                     help="scan strategy of the library (KG_PARTITION): auto picks partitioned probing for large inputs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for "
                                                       "rehearsing the multi-rank path on a one-GPU box)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the ranks (nothing has touched the GPU yet: torch.cuda is not initialised)
+        import socket
+        import subprocess
+        port = args.master_port
+        if not port:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("[bench] --gpus %d without a launcher: starting %d ranks: %s" % (args.gpus, args.gpus, " ".join(cmd)))
+        raise SystemExit(subprocess.call(cmd))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; refusing to print a line whose n_gpus "
+                         "is not the number of ranks that ran" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
 
     os.environ["KG_PARTITION"] = {"auto": "2", "direct": "0", "partitioned": "1"}[args.strategy]
     import torch.distributed as dist
@@ -151,7 +179,7 @@ def main():
     hits = calls = 0
     partitioned = False
     for _ in range(args.steps):
-        st = step(args.gather_hits)
+        st = step(args.gather_hits and world > 1)
         partitioned = bool(st["partitioned"])
         pass_ms["scatter_until_last_chunk"].append(st["ms_part_scatter"]); pass_ms["tag_verify_tail"].append(st["ms_part_verify"])
         scan_ms.append(st["ms_scan"]); total_ms.append(st["ms_total"])
@@ -183,6 +211,7 @@ def main():
     if rank == 0:
         ms_scan = float(np.mean(scan_ms))
         achieved = b_alg * residues / (ms_scan * 1e-3) / 1e9          # GB/s, algorithmic bytes / scan-kernel time
+        achieved_step = b_alg * residues / (elapsed / args.steps) / 1e9   # ... / whole step (rank 0's bytes, max-over-ranks time)
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")        # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tpath) and world == 1:
@@ -223,7 +252,12 @@ def main():
                            hit_bytes_all_ranks=int(hits_all) * 24)),
                        "parallelism": "contig shards x%d, table replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "achieved_step": achieved_step, "frac_step": achieved_step / HBM_PEAK_GBS,
+                         "frac_note": "frac = algorithmic bytes / scan-stage time (HIP events on the library's streams); "
+                                      "frac_step = the same bytes / ms_per_step (ordering, aggregation, records to host / "
+                                      "exchange included)",
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "bound_note": ("priced against HBM as SURVEY 8d prescribes; the partitioned scan moves fewer HBM "
                                         "bytes than the algorithmic count and its passes are bound by VALU/LDS issue "
                                         "(scatter), L2/LDS tag reads (tag pass) and random HBM lines (verification): "

@@ -123,7 +123,8 @@ typedef struct kg_stats {
                                  /* the records are the same either way (EOF == not found)                           */
     int32_t agg_pieces;          /* pieces beyond the first that long containers were cut into for gatherHits (cuts  */
                                  /* at gaps > maxGap, where the reference's list restarts anyway: KGJ:477-484)       */
-    int32_t reserved0;
+    int32_t part_levels;         /* partitioned only: 1 = tags probed in the L2 (bucket_tag_kernel), 2 = entries cut once more  */
+                                 /* by sub-bucket and tags probed in LDS (kg_partition2.hpp)                                   */
 } kg_stats;
 
 typedef struct kg_table  kg_table;

@@ -54,7 +54,7 @@ class KgStats(C.Structure):
                 ("partitioned", C.c_int32), ("ms_part_scatter", C.c_float), ("ms_part_tag", C.c_float),
                 ("ms_part_verify", C.c_float), ("fallback", C.c_int32), ("part_chunks", C.c_int32),
                 ("part_buckets", C.c_int32), ("part_shift", C.c_int32), ("lookup_ran_off", C.c_int32),
-                ("agg_pieces", C.c_int32), ("reserved0", C.c_int32)]
+                ("agg_pieces", C.c_int32), ("part_levels", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}

@@ -241,40 +241,48 @@ __device__ __forceinline__ uint32_t dna_code(uint32_t c)
     return u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : (u == 'T' || u == 'U') ? 3u : 4u;
 }
 
-// The encode stage is table driven and branch free.  Residue codes travel as dwords with "not an amino acid"
-// (KGJ:111-175 code 20; stop codons, codons with a non-ACGTU base) = kBadCode = 2^20.  A 4-residue half code is
-//     c0 * 8000 + c1 * 400 + c2 * 20 + c3   (mod 2^32),
-// < 160000 < 2^20 when all four are valid; with bad residues it is (k mod 4096) * 2^20 + (something < 160000),
-// k a non-empty subset sum of {8000, 400, 20, 1}: none of the 15 sums is a multiple of 4096, so a half code is
-// valid iff it is < 2^20 and no per-residue compare is needed (encodedKmer's early return, KGJ:283-285).
-constexpr uint32_t kBadCode = 1u << 20;
-__device__ __forceinline__ bool half_ok(uint32_t a, uint32_t b) { return ((a | b) >> 20) == 0u; }
-__device__ __forceinline__ uint32_t half_code(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
+// The encode stage is table driven and branch free, and works on BYTES: a residue / codon code is one byte, 0..19 for
+// an amino acid (toAminoAcidOff, KGJ:111-175) and kBadByte for everything else (code 20: stop codons, codons with a
+// non-ACGTU base, non-residue characters).  The eight codes of a window are eight consecutive bytes of LDS, fetched
+// with ONE (unaligned) 8-byte read; v_dot4_u32_u8 folds two of them at a time:
+//     half code = c0 * 8000 + c1 * 400 + c2 * 20 + c3 = (c0 * 20 + c1) * 400 + (c2 * 20 + c3)      (< 160000)
+// and a window is valid iff none of its bytes has the kBadByte bit (encodedKmer's early return, KGJ:283-285).
+// Per block and lane this is ~27 LDS instructions (the dword-per-code version it replaces needed ~88, and 3.7 KB of
+// LDS per wave instead of 0.7: the scatter pass is LDS-bound, profiles/r02_pipeline.md section 3).
+constexpr uint32_t kBadByte = 0x80u;
+__device__ __forceinline__ uint32_t dot4(uint32_t bytes, uint32_t weights, uint32_t acc = 0u)
 {
-    return __umul24(c0, 8000u) + __umul24(c1, 400u) + __umul24(c2, 20u) + c3;
+    return __builtin_amdgcn_udot4(bytes, weights, acc, false);
+}
+// bytes (c0, c1, c2, c3) of w, c0 lowest -> c0 * 8000 + c1 * 400 + c2 * 20 + c3
+__device__ __forceinline__ uint32_t half_up(uint32_t w)
+{
+    return __umul24(dot4(w, 0x00000114u), 400u) + dot4(w, 0x01140000u);
+}
+// the same with c3 the most significant: c3 * 8000 + c2 * 400 + c1 * 20 + c0
+__device__ __forceinline__ uint32_t half_down(uint32_t w)
+{
+    return __umul24(dot4(w, 0x14010000u), 400u) + dot4(w, 0x00001401u);
 }
 
 // Lookup tables shared by the waves of a workgroup (built once per workgroup by encode_init).
 struct EncTablesDna {
-    uint32_t fwd[128];    // [b0*25 + b1*5 + b2] (base codes 0..4): code of codon b0 b1 b2 (translate, KGJ:320-343)
-    uint32_t rev[128];    // same index: code of the reverse-complement codon compl(b2) compl(b1) compl(b0) (KGJ:263-272)
+    uint16_t codon[128];  // [b0*25 + b1*5 + b2] (base codes 0..4): low byte = code of codon b0 b1 b2 (translate, KGJ:320-343),
+                          // high byte = code of the reverse-complement codon compl(b2) compl(b1) compl(b0) (KGJ:263-272)
     uint8_t base[256];    // dnaChar
 };
 struct EncTablesAa {
-    uint32_t code[256];   // toAminoAcidOff (KGJ:111-175): 0..19, else kBadCode
+    uint8_t code[256];    // toAminoAcidOff (KGJ:111-175): 0..19, else kBadByte
 };
 
 struct __attribute__((aligned(16))) WaveLdsDna {
-    uint32_t H[208];      // '+' half codes: 4 codons starting at base q   (q < 204)
-    uint32_t G[208];      // '-' half codes: 4 reverse-complement codons over bases q..q+11
-    uint32_t F[216];      // code of the forward codon starting at base q   (q < 213)
-    uint32_t R[216];      // code of the reverse-complement codon over bases q..q+2
-    uint8_t bc[232];      // base codes of the block's 215 bases
+    uint8_t bc[240];      // base codes of the block's (up to) 216 bases
+    uint8_t cf[3][80];    // cf[f][t]: code of the forward codon starting at base 3t + f            (t <= 70)
+    uint8_t cr[3][80];    // cr[f][t]: code of the reverse-complement codon over bases 3t + f .. 3t + f + 2
 };
 
 struct __attribute__((aligned(16))) WaveLdsAa {
-    uint32_t H4[80];      // half codes of 4 residues starting at q (q < 68)
-    uint32_t code[80];
+    uint8_t code[80];     // residue codes of the block's (up to) 71 characters
 };
 
 template <bool AA> struct WaveLds;
@@ -288,29 +296,30 @@ __device__ __forceinline__ void encode_init(typename WaveLds<AA>::tables &t, uin
     if constexpr (AA) {
         for (uint32_t b = tid; b < 256; b += n_threads) {
             const uint32_t c = aa_code_of_rt((char)b);
-            t.code[b] = c < 20 ? c : kBadCode;
+            t.code[b] = (uint8_t)(c < 20 ? c : kBadByte);
         }
     } else {
         for (uint32_t b = tid; b < 256; b += n_threads) t.base[b] = (uint8_t)dna_code(b);
         for (uint32_t i = tid; i < 128; i += n_threads) {
             const uint32_t b0 = i / 25u, b1 = (i / 5u) % 5u, b2 = i % 5u;
-            uint32_t f = kBadCode, r = kBadCode;
+            uint32_t f = kBadByte, r = kBadByte;
             if (i < 125 && b0 < 4 && b1 < 4 && b2 < 4) {
                 // codon index c1*16+c2*4+c3 (KGJ:331-337); kCodon16[c1*4+c2] packs the four c3 codes
                 f = (kCodon16[b0 * 4 + b1] >> (b2 * 5)) & 31u;
                 r = (kCodon16[(3 - b2) * 4 + (3 - b1)] >> ((3 - b0) * 5)) & 31u;   // compl code = 3 - code
-                if (f >= 20) f = kBadCode;                                         // stop codon '*' -> code 20
-                if (r >= 20) r = kBadCode;
+                if (f >= 20) f = kBadByte;                                         // stop codon '*' -> code 20
+                if (r >= 20) r = kBadByte;
             }
-            t.fwd[i] = f;
-            t.rev[i] = r;
+            t.codon[i] = (uint16_t)(f | (r << 8));
         }
     }
 }
 
-// The raw characters of one block, 4 per lane (lane q holds characters q, q+64, q+128, q+192 of the block's
-// window; AA blocks use the first two).  Separate from the encode step so that a caller can fetch the next
-// block's characters while it works on the current one.
+// The raw characters of one block.  DNA: raw[0] = the four characters 4 * lane .. 4 * lane + 3 of the block's
+// (up to) 216-character window, one (unaligned) dword load per lane, 'N' behind the end of the sequence (never read
+// from memory: the next sequence, or the end of the caller's buffer, lies there); AA: raw[0], raw[1] = characters
+// lane and lane + 64.  Separate from the encode step so that a caller can fetch the next block's characters while it
+// works on the current one.
 template <bool AA>
 __device__ __forceinline__ void load_block_chars(const uint8_t *__restrict__ seq, const BlockDesc &bd, int lane, uint32_t (&raw)[4])
 {
@@ -326,83 +335,66 @@ __device__ __forceinline__ void load_block_chars(const uint8_t *__restrict__ seq
         raw[2] = raw[3] = 0;
     } else {
         const uint32_t ts = bd.j * kDnaPosPerBlock;
-        const uint32_t nload = min(215u, bd.len - ts);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t q = (uint32_t)lane + 64u * k;
-            raw[k] = q < nload ? seq[soff + ts + q] : (uint32_t)'N';
+        const uint32_t nload = min(216u, bd.len - ts);      // 215 are needed (192 + 23); the 216th completes the last dword
+        const uint32_t at = 4u * (uint32_t)lane;
+        uint32_t w = 0x4E4E4E4Eu;                           // "NNNN"
+        const uint8_t *p = seq + soff + ts + at;
+        if (at + 4u <= nload) {
+            __builtin_memcpy(&w, p, 4);                     // one global_load_dword at byte alignment
+        } else if (at < nload) {                            // the last characters of the sequence (one lane per sequence)
+            for (uint32_t k = 0; at + k < nload; k++) w = (w & ~(0xFFu << (8u * k))) | ((uint32_t)p[k] << (8u * k));
         }
+        raw[0] = w;
+        raw[1] = raw[2] = raw[3] = 0;
     }
 }
 
-// Leave the 4-residue half codes of one block in LDS (all lanes of the wave), from its raw characters.
+// Leave the residue / codon codes of one block in LDS (all lanes of the wave), from its raw characters.
 template <bool AA>
 __device__ __forceinline__ void encode_chars(typename WaveLds<AA>::type &l, const typename WaveLds<AA>::tables &t,
                                              const uint32_t (&raw)[4], int lane)
 {
     if constexpr (AA) {
         // ---- protein: windows i = 64j + lane
-        uint32_t c[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) c[k] = t.code[raw[k] & 255u];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const uint32_t q = (uint32_t)lane + 64u * k;
-            if (k < 1 || q < 72) l.code[q] = c[k];
+            const uint8_t c = t.code[raw[k] & 255u];
+            if (k < 1 || q < 72) l.code[q] = c;
         }
-        wave_sync();
-        uint32_t h[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const uint32_t q = min((uint32_t)lane + 64u * k, 67u);
-            h[k] = half_code(l.code[q], l.code[q + 1], l.code[q + 2], l.code[q + 3]);
-        }
-        l.H4[lane] = h[0];
-        if (lane < 4) l.H4[lane + 64] = h[1];
         wave_sync();
     } else {
-        // ---- DNA: 215 bases -> base codes, codon codes for both strands, then 4-codon half codes
-        uint32_t c[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) c[k] = t.base[raw[k] & 255u];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t q = (uint32_t)lane + 64u * k;
-            if (k < 3 || q < 232) l.bc[q] = (uint8_t)c[k];
+        // ---- DNA: 216 bases -> base codes (four per lane, one dword store), then the codon codes of both strands
+        {
+            const uint32_t w = raw[0];
+            const uint32_t c = (uint32_t)t.base[w & 255u] | ((uint32_t)t.base[(w >> 8) & 255u] << 8) |
+                               ((uint32_t)t.base[(w >> 16) & 255u] << 16) | ((uint32_t)t.base[w >> 24] << 24);
+            if (lane < 60) *reinterpret_cast<uint32_t *>(&l.bc[4 * lane]) = c;
         }
         wave_sync();
-        // the four passes of each stage are unrolled with clamped reads and predicated writes, so that all LDS
-        // reads of a stage are in flight together (a wave's block is otherwise a chain of ~16 LDS round trips)
+        // codon q = lane + 64k (q <= 212): its three base codes are three bytes of one (unaligned) dword read, the table
+        // index b0*25 + b1*5 + b2 is one v_dot4; all four reads are in flight together (clamped reads, predicated writes)
         {
-            uint32_t i[4];
+            uint32_t idx[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t q = min((uint32_t)lane + 64u * k, 212u);
-                i[k] = __umul24(__umul24(l.bc[q], 5u) + l.bc[q + 1], 5u) + l.bc[q + 2];
+                uint32_t x;
+                __builtin_memcpy(&x, &l.bc[q], 4);
+                idx[k] = dot4(x, 0x00010519u);
             }
-            uint32_t f[4], r[4];
+            uint32_t cw[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { f[k] = t.fwd[i[k]]; r[k] = t.rev[i[k]]; }
+            for (int k = 0; k < 4; k++) cw[k] = t.codon[idx[k]];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t q = (uint32_t)lane + 64u * k;
-                if (k < 3 || q < 213) { l.F[q] = f[k]; l.R[q] = r[k]; }
-            }
-        }
-        wave_sync();
-        {
-            uint32_t h[4], g[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t q = min((uint32_t)lane + 64u * k, 203u);
-                h[k] = half_code(l.F[q], l.F[q + 3], l.F[q + 6], l.F[q + 9]);
-                // on the '-' strand the codon over the highest bases comes first
-                g[k] = half_code(l.R[q + 9], l.R[q + 6], l.R[q + 3], l.R[q]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t q = (uint32_t)lane + 64u * k;
-                if (k < 3 || q < 204) { l.H[q] = h[k]; l.G[q] = g[k]; }
+                const uint32_t tt = (q * 171u) >> 9;         // q / 3 for q < 256
+                const uint32_t f = q - 3u * tt;
+                if (k < 3 || q < 213) {
+                    l.cf[0][f * 80u + tt] = (uint8_t)cw[k];
+                    l.cr[0][f * 80u + tt] = (uint8_t)(cw[k] >> 8);
+                }
             }
         }
         wave_sync();
@@ -419,26 +411,32 @@ __device__ __forceinline__ void encode_block(typename WaveLds<AA>::type &l, cons
 }
 
 // encodedKmer (KGJ:274-292) of the lane's window in row r (wave-uniform; DNA: strand r/3, phase r%3), as its
-// two half codes: value = hi * 160000 + lo.
+// two half codes: value = hi * 160000 + lo.  Returns whether the window is a query k-mer.
 template <bool AA>
 __device__ __forceinline__ bool row_halves(const typename WaveLds<AA>::type &l, int r, int lane, const BlockDesc &bd,
                                            uint32_t *hi_out, uint32_t *lo_out)
 {
     if constexpr (AA) {
-        uint32_t hi = l.H4[lane], lo = l.H4[lane + 4];
-        uint32_t i = bd.j * kAaWinPerBlock + lane;
-        *hi_out = hi; *lo_out = lo;
+        uint2 v;
+        __builtin_memcpy(&v, &l.code[lane], 8);              // the window's eight residue codes
+        const uint32_t i = bd.j * kAaWinPerBlock + lane;
+        *hi_out = half_up(v.x); *lo_out = half_up(v.y);
         // queried iff i < len - 8 (KGJ:912: i < pIseq.length - K -- the last window is never queried)
-        return half_ok(hi, lo) & ((uint64_t)i + 8 < (uint64_t)bd.len);
+        return (((v.x | v.y) & 0x80808080u) == 0u) & ((uint64_t)i + 8 < (uint64_t)bd.len);
     } else {
         const bool minus = r >= 3;
-        const uint32_t pl = 3u * lane + (uint32_t)(minus ? r - 3 : r);
-        const uint32_t *hc = minus ? l.G : l.H;
-        uint32_t a = hc[pl], b = hc[pl + 12];
-        // '+': first four codons are the high half; '-': the codons over the higher bases are
-        *hi_out = minus ? b : a;
-        *lo_out = minus ? a : b;
-        return half_ok(a, b);
+        const uint32_t f = (uint32_t)(minus ? r - 3 : r);
+        // window over forward bases p .. p+23, p = 3 * lane + f: its eight codons are the bytes lane .. lane+7 of phase f
+        const uint8_t *src = (minus ? &l.cr[0][0] : &l.cf[0][0]) + f * 80u + (uint32_t)lane;
+        uint2 v;
+        __builtin_memcpy(&v, src, 8);
+        if (minus) {
+            // on the '-' strand the codon over the highest bases comes first (KGJ:263-272, 1068-1072)
+            *hi_out = half_down(v.y); *lo_out = half_down(v.x);
+        } else {
+            *hi_out = half_up(v.x); *lo_out = half_up(v.y);
+        }
+        return ((v.x | v.y) & 0x80808080u) == 0u;
     }
 }
 

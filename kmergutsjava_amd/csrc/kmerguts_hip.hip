@@ -8,6 +8,7 @@
 #include "kg_device.hpp"
 #include "kg_aggregate.hpp"
 #include "kg_partition.hpp"
+#include "kg_partition2.hpp"
 
 #include <fcntl.h>
 #include <unistd.h>
@@ -179,6 +180,7 @@ struct kg_table {
     uint64_t occupied = 0;
     double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
     size_t scatter_lds[2] = {0, 0};  // dynamic LDS the scatter kernel (DNA / protein) has been allowed so far
+    size_t probe2_lds[2] = {0, 0};   // ... and the second-level probe kernel (without / with counters)
     hipEvent_t ev[8] = {};
     // Pinned host words for the few counters a scan reads back (a hipMemcpyAsync to pageable memory blocks the host per
     // copy; to pinned memory it does not): [0..47] d_pc, [48..79] d_ovfc (as 64 x u32), [80..87] d_totals, [88] CALL total
@@ -893,6 +895,38 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if ((rc = sc.get(&d_pc, 48))) return rc;
         if ((rc = sc.get(&d_partial_c, partial_stride * n_chunks_p))) return rc;
         unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
+        // Second partition level (kg_partition2.hpp): the entries of a bucket are cut once more, by sub-bucket of 2^sshift
+        // slots, and probed against tags held in LDS.  KG_PART_LEVELS: 1 = tag pass out of the L2 (bucket_tag_kernel),
+        // 2 = sub-scatter + LDS probe.  KG_PART_SUBSHIFT: log2 of a sub-bucket's slots (tags = LDS bytes per workgroup).
+        uint32_t levels = env_u32("KG_PART_LEVELS", 1u);
+        uint32_t sshift = std::min(17u, env_u32("KG_PART_SUBSHIFT", 16u));
+        if (sshift + 6 < part_shift) sshift = part_shift - 6;                         // at most kMaxSub sub-buckets per bucket
+        if (sshift + 1 > part_shift) sshift = part_shift - 1;
+        if (levels != 2 || part_shift < 9 || sshift < 8) levels = 1;
+        const uint32_t n_sub = levels == 2 ? 1u << (part_shift - sshift) : 0u;
+        const uint64_t n_sub_total = (uint64_t)part_buckets * n_sub;                  // sub-bucket arrays per chunk
+        const uint32_t n_items2 = levels == 2 ? (uint32_t)((t->limit + (1ull << sshift) - 1) >> sshift) : 0u;
+        uint32_t cap2 = 0;
+        uint64_t *d_ent2 = nullptr;
+        uint32_t *d_cur2 = nullptr;
+        if (levels == 2) {
+            // a sub-bucket's array: 1.25 x the mean if every window of the largest chunk were valid and hashed uniformly, + 6
+            // sigma.  (Slots are value % numSigs: a sub-bucket is ~18 runs of consecutive k-mer values, i.e. of k-mers that share
+            // their first four or five residues, and residue frequencies differ -- six-codon against one-codon amino acids --
+            // so sub-buckets fill far less evenly than uniform hashing would: at 1.0 x, 0.24 % of the entries of the 1 Gbp
+            // bench spilled to the overflow list, where the DNA's 32 % of invalid windows were the only headroom.)
+            const double mean2 = (double)max_chunk * WIN / (double)n_sub_total * (env_u32("KG_PART_SLACK", 100u) / 100.0) * 1.25;
+            cap2 = env_u32("KG_PART_CAP2", (uint32_t)(((uint64_t)(mean2 + 6.0 * std::sqrt(mean2) + 64.0) + 15) / 16 * 16));
+            cap2 = std::max(16u, (cap2 + 15u) / 16u * 16u);
+            if ((rc = sc.get(&d_ent2, (size_t)(n_sub_total * cap2 * n_chunks_p)))) return rc;
+            if ((rc = sc.get(&d_cur2, (size_t)(n_sub_total * n_chunks_p)))) return rc;
+            const size_t tile_lds = ((size_t)1 << sshift) + 16;
+            if (t->probe2_lds[counters ? 1 : 0] < tile_lds) {
+                if (counters) HIP_TRY(hipFuncSetAttribute((const void *)kg::sub_probe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+                else HIP_TRY(hipFuncSetAttribute((const void *)kg::sub_probe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+                t->probe2_lds[counters ? 1 : 0] = tile_lds;
+            }
+        }
         const size_t lds = kg::scatter_lds_bytes<AA>(part_buckets);
         if (t->scatter_lds[AA ? 1 : 0] < lds) {         // once per table (and geometry): the call costs tens of microseconds
             HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -937,6 +971,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 cl.p[5] = d_next; cl.words[5] = (uint64_t)next_stride * n_chunks_p;
                 cl.p[6] = reinterpret_cast<uint32_t *>(d_masks); cl.words[6] = (uint64_t)n_rows * 2;
                 cl.p[7] = nullptr; cl.words[7] = 0;
+                if (levels == 2) { cl.n = 8; cl.p[7] = d_cur2; cl.words[7] = n_sub_total * n_chunks_p; }
                 const uint64_t most = std::max<uint64_t>(cl.words[6], 1) / 4;
                 hipLaunchKernelGGL(kg::clear_many_kernel, dim3((uint32_t)std::min<uint64_t>(4096, (most + 255) / 256 + 1)), dim3(256), 0,
                                    t->stream, cl);
@@ -975,7 +1010,23 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
 #define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
                     candused_c, ccur_c, ccap, d_ctr
 #define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_masks, d_ctr
-                if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
+                if (levels == 2) {
+                    uint64_t *ent2_c = d_ent2 + (uint64_t)c * n_sub_total * cap2;
+                    uint32_t *cur2_c = d_cur2 + (uint64_t)c * n_sub_total;
+                    const uint32_t rpi = std::max(1u, std::min(n_wg, env_u32("KG_SUB_RPI", 16u)));
+                    const uint64_t items1 = (uint64_t)part_buckets * ((n_wg + rpi - 1) / rpi);
+                    const uint32_t grid1 = (uint32_t)std::min<uint64_t>(items1, std::max(1u, env_u32("KG_SUB_GRID", 256u * 4u)));
+                    hipLaunchKernelGGL(kg::sub_scatter_kernel, dim3(grid1), dim3(kg::kSubThreads), 0, s2, ent_c, fill_c, n_wg, cap,
+                                       part_buckets, part_shift, sshift, rpi, next_c, ent2_c, cur2_c, cap2, ovfc_c, ovf_cap,
+                                       ovf_bucket_c, ovf_ent_c);
+                    const size_t tile_lds = ((size_t)1 << sshift) + 16;
+                    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / (tile_lds + 256)));
+                    const uint32_t grid2 = std::min(n_items2, std::max(1u, env_u32("KG_PROBE2_GRID", 256u * per_cu)));
+#define KG_TAG2_ARGS t->d_tags, t->limit, ent2_c, cur2_c, cap2, n_items2, part_shift, sshift, next_c + 64, cand_c, candused_c, ccur_c, ccap, d_ctr
+                    if (counters) hipLaunchKernelGGL((kg::sub_probe_kernel<true>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
+                    else hipLaunchKernelGGL((kg::sub_probe_kernel<false>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
+#undef KG_TAG2_ARGS
+                } else if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
                 else hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
                 HIP_TRY(hipEventRecord(t->pev[2 * c + 1], s2));
                 HIP_TRY(hipStreamWaitEvent(s3, t->pev[2 * c + 1], 0));
@@ -1033,10 +1084,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             if (getenv("KG_DEBUG"))
                 fprintf(stderr, "[kg] partition attempt %d: %u chunks (largest %llu of %llu blocks), overflow groups <= %u (cap %u), hit list <= %llu "
                                 "(cap %llu), candidates <= %llu (cap %llu), regions/chunk %llu x %u entries, %u buckets, shift %u, %u scatter "
-                                "workgroups, hits %llu\n",
+                                "workgroups, hits %llu, levels %u (sub-bucket shift %u, %u entries each)\n",
                         attempt, n_chunks_p, (unsigned long long)max_chunk, (unsigned long long)nblocks, max_ovf, ovf_cap,
                         (unsigned long long)need_u, (unsigned long long)ucap, (unsigned long long)need_c, (unsigned long long)ccap,
-                        (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg, (unsigned long long)h_pc[16 + n_chunks_p]);
+                        (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg, (unsigned long long)h_pc[16 + n_chunks_p], levels, sshift, cap2);
             if (guard) { too_skewed = true; st.fallback = 2; break; }    // the scatter pass's spin guard fired: direct path
             if (max_ovf > ovf_cap) { too_skewed = true; st.fallback = 1; break; }   // more overflow than provisioned: direct path
             n_hits = h_pc[16 + n_chunks_p];
@@ -1066,6 +1117,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             part_done = true;
             st.partitioned = 1;
             st.part_chunks = (int32_t)n_chunks_p; st.part_buckets = (int32_t)part_buckets; st.part_shift = (int32_t)part_shift;
+            st.part_levels = (int32_t)levels;
         }
     }
     if (!part_done) {

@@ -8,7 +8,7 @@ own k-mers and the table, and the aggregation state is per sequence (KGJ:528, 54
 step is therefore one gather of variable-length record buffers at the end; there is no
 all-reduce.
 
-The exchange (gather_records): one all_gather of the buffer sizes, then ONE group of point-to-point
+The exchange (gather_records): one gather of the buffer sizes to rank 0, then ONE group of point-to-point
 transfers towards rank 0 -- only rank 0 allocates receive buffers (exact sizes, no padding), the
 senders hand over the library's own device buffers (ScanResult.device_view: no host hop on the RCCL
 path).  CALL / OTU records are a few KB and are put back in FASTA order on the host; hit records
@@ -67,15 +67,17 @@ def _as_u8(x, device) -> torch.Tensor:
 def gather_buffers(bufs: List[torch.Tensor], dst: int = 0) -> Optional[List[List[torch.Tensor]]]:
     """Gather K 1-D uint8 buffers of rank-dependent length to rank dst (all ranks call, same K).
     Returns on dst: out[k][r] = buffer k of rank r (its own buffers are passed through, not copied); None elsewhere.
-    Sizes travel in one all_gather; the payload in one batch of point-to-point transfers, so only dst allocates."""
+    Sizes travel in one gather towards dst -- only dst needs them, and only dst pays the host round trip that reads
+    them; the senders post their transfers at once -- the payload in one batch of point-to-point transfers, so only dst
+    allocates."""
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = bufs[0].device
     mine = torch.tensor([b.numel() for b in bufs], dtype=torch.int64, device=dev)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)
-    sizes = torch.stack(parts).cpu().tolist()                # [world][K]
     ops, out = [], None
     if rank == dst:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.gather(mine, parts, dst=dst)
+        sizes = torch.stack(parts).cpu().tolist()            # [world][K]
         out = [[None] * world for _ in bufs]
         for r in range(world):
             for k, b in enumerate(bufs):
@@ -86,6 +88,7 @@ def gather_buffers(bufs: List[torch.Tensor], dst: int = 0) -> Optional[List[List
                     if sizes[r][k]:
                         ops.append(dist.P2POp(dist.irecv, out[k][r], r))
     else:
+        dist.gather(mine, None, dst=dst)
         for b in bufs:
             if b.numel():
                 ops.append(dist.P2POp(dist.isend, b, dst))

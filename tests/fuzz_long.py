@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long differential fuzz against the CPU oracle (test infrastructure; not collected by pytest):
     python tests/fuzz_long.py [n_workloads=400] [first_seed=1000]
-Every workload of tests/fuzz_workloads.py through both scan strategies, records, event bytes, counters and flags compared
+Every workload of tests/fuzz_workloads.py through the three scan strategies, records, event bytes, counters and flags compared
 with the oracle.  Prints one JSON summary line; exit code 1 on the first difference."""
 import json
 import os
@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from fuzz_workloads import workloads          # noqa: E402
 from helpers import assert_same_records       # noqa: E402
 
-KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_SLACK", "KG_TEST_TINY_LISTS", "KG_PART_OVF_GROUPS")
+KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_SLACK", "KG_TEST_TINY_LISTS", "KG_PART_OVF_GROUPS",
+         "KG_PART_LEVELS", "KG_PART_SUBSHIFT", "KG_PART_CAP2", "KG_SUB_RPI")
 
 
 def main():
@@ -28,14 +29,16 @@ def main():
             p = w["params"]
             ora = kgo.run(w["img"], w["raw"], w["off"], lookup_mode=1, **p)
             with hotpath.SignatureTable.from_bytes(w["img"]) as tab:
-                for mode in ("0", "1"):
+                for mode in ("0", "1", "2"):           # direct, partitioned, partitioned with the second level
                     for k in KNOBS:
                         os.environ.pop(k, None)
-                    os.environ["KG_PARTITION"] = mode
-                    if mode == "1":
+                    os.environ["KG_PARTITION"] = "0" if mode == "0" else "1"
+                    if mode != "0":
                         os.environ.update(w["env"])
+                    if mode == "2":
+                        os.environ.update(w["env2"])
                     with tab.scan(w["raw"], w["off"], hotpath.Params(counters=True, **p)) as r:
-                        assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s" % (seed, w["it"], mode, w["env"]))
+                        assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s %s" % (seed, w["it"], mode, w["env"], w["env2"] if mode == "2" else ""))
                         assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
                         n_part += r.stats["partitioned"]
             done += 1
@@ -43,7 +46,7 @@ def main():
             hits += len(ora["hits"])
             if done >= n:
                 break
-    print(json.dumps({"workloads": done, "scans": 2 * done, "ran_partitioned": n_part, "oracle_hits": hits, "oracle_calls": calls,
+    print(json.dumps({"workloads": done, "scans": 3 * done, "ran_partitioned": n_part, "oracle_hits": hits, "oracle_calls": calls,
                       "all_identical": True}))
 
 

@@ -52,4 +52,11 @@ def workloads(iters, seed):
             env["KG_TEST_TINY_LISTS"] = "1"
         if rng.integers(0, 8) == 0:
             env["KG_PART_OVF_GROUPS"] = str(int(rng.choice([1, 64])))
-        yield dict(it=it, aa=aa, num_sigs=num_sigs, load=load, img=img, raw=raw, off=off, params=params, env=env)
+        # the second partition level (used by the callers' "2" mode): sub-bucket size, and now and then sub-bucket arrays
+        # far too small, so that entries spill to the overflow list
+        env2 = {"KG_PART_LEVELS": "2", "KG_PART_SUBSHIFT": str(int(rng.choice([8, 9, 10, 12, 16])))}
+        if rng.integers(0, 3) == 0:
+            env2["KG_PART_CAP2"] = str(int(rng.choice([16, 64, 256])))
+        if rng.integers(0, 4) == 0:
+            env2["KG_SUB_RPI"] = str(int(rng.choice([1, 3, 256])))
+        yield dict(env2=env2, it=it, aa=aa, num_sigs=num_sigs, load=load, img=img, raw=raw, off=off, params=params, env=env)

@@ -24,13 +24,16 @@ def assert_same_records(gpu, ora, what=""):
     assert gpu.stats["lookup_ran_off"] == int(ora["lookup_aborted"]), what + " lookup_ran_off"
     import os
     mode = os.environ.get("KG_PARTITION")
-    knobs = os.environ.get("KG_PART_OVF_GROUPS") is not None or os.environ.get("KG_PART_SLACK") is not None
+    knobs = any(os.environ.get(k) is not None for k in ("KG_PART_OVF_GROUPS", "KG_PART_SLACK", "KG_PART_CAP2"))
     if not knobs:       # 1 = overflow beyond the list, 2 = spin guard of the scatter pass: never without a forcing knob
         assert gpu.stats["fallback"] == 0, "%s: partitioned attempt thrown away (fallback %d)" % (what, gpu.stats["fallback"])
     if mode == "0":
         assert gpu.stats["partitioned"] == 0, what + ": direct strategy requested"
     if mode == "1" and gpu.stats["n_blocks"] > 0 and os.environ.get("KG_PART_OVF_GROUPS") is None and os.environ.get("KG_PART_SLACK") is None and _partition_fits(gpu.stats):
         assert gpu.stats["partitioned"] == 1, what + ": the partitioned strategy fell back to direct probing"
+    if gpu.stats["partitioned"] == 1:
+        want = 2 if os.environ.get("KG_PART_LEVELS") == "2" and gpu.stats["part_shift"] >= 9 else 1
+        assert gpu.stats["part_levels"] == want, "%s: partition levels %d, wanted %d" % (what, gpu.stats["part_levels"], want)
 
 
 def _partition_fits(stats) -> bool:
@@ -42,7 +45,7 @@ def _partition_fits(stats) -> bool:
         shift -= 1
     while ((num_sigs + (1 << shift) - 1) >> shift) > 1024:
         shift += 1
-    enc = 3632 * 16 + 1280 if stats["n_containers"] != stats["n_seqs"] else 640 * 16 + 1024   # WaveLds<AA> x 16 + tables
+    enc = 720 * 16 + 512 if stats["n_containers"] != stats["n_seqs"] else 80 * 16 + 256        # WaveLds<AA> x 16 + tables
     while enc + ((num_sigs + (1 << shift) - 1) >> shift) * 140 > 160 * 1024:
         shift += 1
     return shift < 32 and qmax < (1 << (32 - shift)) and stats["n_blocks"] <= (1 << 23) and 64 <= num_sigs < (1 << 31)

@@ -1,6 +1,6 @@
 """Differential fuzz (tests/fuzz_workloads.py: random tables, sequences with planted signatures and low-complexity
 runs, parameters, forced chunking, tiny regions and lists):
-  * both scan strategies against the CPU oracle, record for record, events included;
+  * the scan strategies (direct, partitioned, partitioned with the second level) against the CPU oracle, record for record, events included;
   * tools/fuzz_strategies.py (direct vs partitioned only, no oracle) as a subprocess."""
 import json
 import os
@@ -14,7 +14,8 @@ from helpers import assert_same_records
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_SLACK", "KG_TEST_TINY_LISTS", "KG_PART_OVF_GROUPS")
+KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_SLACK", "KG_TEST_TINY_LISTS", "KG_PART_OVF_GROUPS",
+         "KG_PART_LEVELS", "KG_PART_SUBSHIFT", "KG_PART_CAP2", "KG_SUB_RPI")
 
 
 @pytest.mark.parametrize("seed", [21, 22])
@@ -25,18 +26,21 @@ def test_both_strategies_against_the_oracle(oracle, monkeypatch, seed):
         p = w["params"]
         ora = oracle.run(w["img"], w["raw"], w["off"], lookup_mode=1, **p)
         with hotpath.SignatureTable.from_bytes(w["img"]) as tab:
-            for mode in ("0", "1"):
+            for mode in ("0", "1", "2"):               # direct, partitioned, partitioned with the second level
                 for k in KNOBS:
                     monkeypatch.delenv(k, raising=False)
-                monkeypatch.setenv("KG_PARTITION", mode)
-                if mode == "1":
+                monkeypatch.setenv("KG_PARTITION", "0" if mode == "0" else "1")
+                if mode != "0":
                     for k, v in w["env"].items():
                         monkeypatch.setenv(k, v)
+                if mode == "2":
+                    for k, v in w["env2"].items():
+                        monkeypatch.setenv(k, v)
                 with tab.scan(w["raw"], w["off"], hotpath.Params(counters=True, **p)) as r:
-                    assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s" % (seed, w["it"], mode, w["env"]))
+                    assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s %s" % (seed, w["it"], mode, w["env"], w["env2"] if mode == "2" else ""))
                     assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
                     n_part += r.stats["partitioned"]
-    assert n_part >= 15
+    assert n_part >= 30
 
 
 def test_strategies_agree_on_random_workloads():

@@ -12,11 +12,16 @@ from helpers import assert_same_records, plant
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["direct", "partitioned"])
+@pytest.fixture(autouse=True, params=["direct", "partitioned", "partitioned2"])
 def strategy(request, monkeypatch):
-    """Every parity test runs with both scan strategies: direct probing and partitioned probing
-    (KG_PARTITION=1 forces the bucketed path even on tables small enough for the direct one)."""
-    monkeypatch.setenv("KG_PARTITION", "1" if request.param == "partitioned" else "0")
+    """Every parity test runs with the three scan strategies: direct probing, partitioned probing (KG_PARTITION=1
+    forces the bucketed path even on tables small enough for the direct one) with the tags probed in the L2, and
+    with the second partition level (KG_PART_LEVELS=2: sub-scatter + tags probed in LDS; 2^9-slot sub-buckets so that
+    the small test tables have several per bucket)."""
+    monkeypatch.setenv("KG_PARTITION", "0" if request.param == "direct" else "1")
+    monkeypatch.setenv("KG_PART_LEVELS", "2" if request.param == "partitioned2" else "1")
+    if request.param == "partitioned2":
+        monkeypatch.setenv("KG_PART_SUBSHIFT", "9")
     return request.param
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/kstat.sh <tag> [ENV=VAL ...]   -- kernel durations of tools/one_scan.py under rocprofv3 (tuning aid)
 tag=$1; shift
-out=gpurun_out/r02/kstat/$tag; mkdir -p $out
+out=gpurun_out/${KSTAT_ROUND:-r03}/kstat/$tag; mkdir -p $out
 export TMPDIR=/tmp SW_REPS=${SW_REPS:-3}
 for kv in "$@"; do export "$kv"; done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 ${KSTAT_TOOL:-tools/one_scan.py} > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
@@ -11,7 +11,7 @@ import csv,sys,json,glob,os
 out,tag=sys.argv[1],sys.argv[2]
 f=glob.glob(out+'/**/*kernel_stats.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
-keys=os.environ.get('KSTAT_KEYS','bucket_tag,part_scatter,verify_kernel,place_unordered,row_info,rows_from').split(',')
+keys=os.environ.get('KSTAT_KEYS','bucket_tag,part_scatter,sub_scatter,sub_probe,verify_kernel,overflow_probe,place_unordered,row_info,rows_from').split(',')
 d={}
 for r in rows:
     for k in keys:

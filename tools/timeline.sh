@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/timeline.sh <tag> <python tool> [ENV=VAL ...] -- kernel timeline of the tool's LAST scan (tuning aid)
 tag=$1; tool=$2; shift 2
-out=gpurun_out/r02/timeline/$tag; mkdir -p $out
+out=gpurun_out/${KSTAT_ROUND:-r03}/timeline/$tag; mkdir -p $out
 export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 $tool > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
