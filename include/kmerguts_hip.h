@@ -13,7 +13,19 @@
  * library is owned by the library and released by kg_result_free / kg_table_close.
  * A kg_table is read-only after creation and may be shared by host threads; at most one
  * kg_scan* may be in flight per kg_table at a time (the reference's instance is not
- * re-entrant either, KGJ:838).
+ * re-entrant either, KGJ:838): a second concurrent kg_scan* on the same table returns
+ * KG_ERR_BUSY without touching anything.
+ *
+ * Environment variables read by kg_scan* (tuning and test hooks, none needed in production; every
+ * one is read at the start of each call, so a test can change them between calls):
+ *   KG_PARTITION (0 direct / 1 partitioned whenever possible / 2 auto), KG_PART_LEVELS (1 / 2), KG_PART_SHIFT,
+ *   KG_PART_SUBSHIFT, KG_PART_CHUNKS, KG_PART_MIN_CHUNK_BLOCKS, KG_PART_WGS, KG_PART_SLACK, KG_PART_CAP2,
+ *   KG_PART_OVF_GROUPS, KG_PART_TAPER, KG_PROBE_GRID, KG_PROBE_GRAB, KG_PROBE2_GRID, KG_SUB_GRID, KG_SUB_RPI,
+ *   KG_VERIFY_GRID, KG_SCAN_GRID, KG_SCAN_RPG, KG_STAGE_CHUNK, KG_AGG_PIECES, KG_AGG_BLOCK_SHIFT: geometry of the
+ *   scan strategies (kmerguts_hip.hip, scan_impl); results never depend on them.  KG_DEBUG: one stderr line per attempt.
+ *   TEST HOOKS (used by tests/ only): KG_TEST_TINY_LISTS=1 starts the hit / candidate lists at one chunk, so that the
+ *   resize-and-rerun path runs; KG_TEST_FAIL_ALLOC=n makes the n-th device allocation of the call fail with
+ *   KG_ERR_NOMEM, so that the error paths can be checked for leaks (kg_table_live_device_bytes).
  */
 #ifndef KMERGUTS_HIP_H
 #define KMERGUTS_HIP_H
@@ -33,6 +45,7 @@ extern "C" {
 #define KG_ERR_NOMEM       (-5)
 #define KG_ERR_UNSUPPORTED (-6)   /* parameters on which the reference itself throws (minHits < 2) */
 #define KG_ERR_LIMIT       (-7)   /* one call exceeds 2^32-1 windows or 2^31-1 window blocks       */
+#define KG_ERR_BUSY        (-8)   /* another kg_scan* is in flight on the same kg_table            */
 
 /* KGJ:85-99 */
 #define KG_K                8
@@ -124,7 +137,8 @@ typedef struct kg_stats {
     int32_t agg_pieces;          /* pieces beyond the first that long containers were cut into for gatherHits (cuts  */
                                  /* at gaps > maxGap, where the reference's list restarts anyway: KGJ:477-484)       */
     int32_t part_levels;         /* partitioned only: 1 = tags probed in the L2 (bucket_tag_kernel), 2 = entries cut once more  */
-                                 /* by sub-bucket and tags probed in LDS (kg_partition2.hpp)                                   */
+                                 /* by sub-bucket and tags probed in LDS (kg_partition2.hpp), 3 = cut once more and looked up  */
+                                 /* in the table's home index held in LDS (sub_index_kernel)                                   */
 } kg_stats;
 
 typedef struct kg_table  kg_table;
@@ -143,6 +157,9 @@ int kg_table_from_memory(const void *image, size_t nbytes, int device, kg_table 
 int kg_table_from_device(const void *d_entries, int64_t num_sigs, int device, kg_table **out);
 /* header fields (KmerMemoryInfo, KGJ:1194-1198) and the number of occupied slots */
 int kg_table_info(const kg_table *t, int64_t *num_sigs, int64_t *entry_size, int64_t *version, int64_t *occupied);
+/* Bytes of device scratch / result blocks the table's block cache has handed out and not got back: the blocks of the
+ * results still open, 0 when there are none (also after a failed kg_scan*: nothing may be left behind). */
+int64_t kg_table_live_device_bytes(kg_table *t);
 void kg_table_close(kg_table *t);
 
 /* ---- the hot path: replaces prepareQuery/addKmers (KGJ:1051-1074, 900-922), the query sort

@@ -14,13 +14,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KG_LIB_PATH") or os.path.join(HERE, "libkmerguts_hip.so")   # KG_LIB_PATH: tuning builds only
 
 KG_OK = 0
+KG_ERR_NOMEM = -5
+KG_ERR_BUSY = -8
 KG_F_COUNTERS = 1
 KG_F_SKIP_AGGREGATE = 2
 KG_OI_BUFSZ = 5
 
 # every symbol include/kmerguts_hip.h declares
 EXPORTS = (
-    "kg_table_open", "kg_table_from_memory", "kg_table_from_device", "kg_table_info", "kg_table_close",
+    "kg_table_open", "kg_table_from_memory", "kg_table_from_device", "kg_table_info", "kg_table_live_device_bytes", "kg_table_close",
     "kg_scan", "kg_scan_device", "kg_aggregate_hits", "kg_process_set_of_hits", "kg_result_stats", "kg_result_hits", "kg_result_container_hit_start",
     "kg_result_calls", "kg_result_container_call_start", "kg_result_otu", "kg_result_hit_events",
     "kg_result_container_tail_events", "kg_result_copy_hits", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu",
@@ -94,6 +96,8 @@ def load() -> C.CDLL:
     lib.kg_table_from_memory.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(vp)]
     lib.kg_table_from_device.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(vp)]
     lib.kg_table_info.argtypes = [vp, i64p, i64p, i64p, i64p]
+    lib.kg_table_live_device_bytes.argtypes = [vp]
+    lib.kg_table_live_device_bytes.restype = C.c_int64
     lib.kg_table_close.argtypes = [vp]
     lib.kg_table_close.restype = None
     lib.kg_scan.argtypes = [vp, C.POINTER(KgParams), vp, vp, C.c_int64, C.POINTER(vp)]

@@ -254,6 +254,34 @@ __device__ __forceinline__ uint32_t dot4(uint32_t bytes, uint32_t weights, uint3
 {
     return __builtin_amdgcn_udot4(bytes, weights, acc, false);
 }
+// Eight (or four) consecutive bytes of LDS at an arbitrary byte address (base 4-byte aligned).
+// KG_ENC_UNALIGNED: one unaligned ds_read_b64 / b32 (gfx950 serves them, tools/lds_unaligned.hip); otherwise the
+// aligned dwords around the address and v_alignbyte.
+__device__ __forceinline__ uint2 lds_bytes8(const uint8_t *base, uint32_t at)
+{
+    uint2 v;
+#ifdef KG_ENC_UNALIGNED
+    __builtin_memcpy(&v, base + at, 8);
+#else
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (at & ~3u));
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], sh = at & 3u;
+    v.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+#endif
+    return v;
+}
+__device__ __forceinline__ uint32_t lds_bytes4(const uint8_t *base, uint32_t at)
+{
+#ifdef KG_ENC_UNALIGNED
+    uint32_t x;
+    __builtin_memcpy(&x, base + at, 4);
+    return x;
+#else
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (at & ~3u));
+    return __builtin_amdgcn_alignbyte(p[1], p[0], at & 3u);
+#endif
+}
+
 // bytes (c0, c1, c2, c3) of w, c0 lowest -> c0 * 8000 + c1 * 400 + c2 * 20 + c3
 __device__ __forceinline__ uint32_t half_up(uint32_t w)
 {
@@ -379,9 +407,7 @@ __device__ __forceinline__ void encode_chars(typename WaveLds<AA>::type &l, cons
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t q = min((uint32_t)lane + 64u * k, 212u);
-                uint32_t x;
-                __builtin_memcpy(&x, &l.bc[q], 4);
-                idx[k] = dot4(x, 0x00010519u);
+                idx[k] = dot4(lds_bytes4(l.bc, q), 0x00010519u);
             }
             uint32_t cw[4];
 #pragma unroll
@@ -417,8 +443,7 @@ __device__ __forceinline__ bool row_halves(const typename WaveLds<AA>::type &l, 
                                            uint32_t *hi_out, uint32_t *lo_out)
 {
     if constexpr (AA) {
-        uint2 v;
-        __builtin_memcpy(&v, &l.code[lane], 8);              // the window's eight residue codes
+        const uint2 v = lds_bytes8(l.code, (uint32_t)lane);   // the window's eight residue codes
         const uint32_t i = bd.j * kAaWinPerBlock + lane;
         *hi_out = half_up(v.x); *lo_out = half_up(v.y);
         // queried iff i < len - 8 (KGJ:912: i < pIseq.length - K -- the last window is never queried)
@@ -427,9 +452,7 @@ __device__ __forceinline__ bool row_halves(const typename WaveLds<AA>::type &l, 
         const bool minus = r >= 3;
         const uint32_t f = (uint32_t)(minus ? r - 3 : r);
         // window over forward bases p .. p+23, p = 3 * lane + f: its eight codons are the bytes lane .. lane+7 of phase f
-        const uint8_t *src = (minus ? &l.cr[0][0] : &l.cf[0][0]) + f * 80u + (uint32_t)lane;
-        uint2 v;
-        __builtin_memcpy(&v, src, 8);
+        const uint2 v = lds_bytes8(minus ? &l.cr[0][0] : &l.cf[0][0], f * 80u + (uint32_t)lane);
         if (minus) {
             // on the '-' strand the codon over the highest bases comes first (KGJ:263-272, 1068-1072)
             *hi_out = half_down(v.y); *lo_out = half_down(v.x);
@@ -893,6 +916,8 @@ __global__ __launch_bounds__(256) void clear_many_kernel(ClearList l)
 
 // ---------------------------------------------------------------------------------------
 // tag array from the 24-byte records (one pass over the table at load time)
+// occupied[0] += occupied slots; occupied[1] = max(1 + index of the last EMPTY slot below limit) = the first slot of the
+// occupied run that ends at the end of the record stream (0: no empty slot at all; limit: the last record is empty).
 __global__ void build_tags_kernel(const uint8_t *entries, uint64_t limit, uint64_t n_tags, uint64_t num_sigs, uint64_t magic,
                                   uint8_t *tags, unsigned long long *occupied)
 {
@@ -900,7 +925,7 @@ __global__ void build_tags_kernel(const uint8_t *entries, uint64_t limit, uint64
     tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic; tab.m35 = 0;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long occ = 0;
+    unsigned long long occ = 0, tail = 0;
     for (; i < n_tags; i += stride) {
         uint32_t t = kTagEmpty;
         if (i < limit) {
@@ -915,9 +940,68 @@ __global__ void build_tags_kernel(const uint8_t *entries, uint64_t limit, uint64
             }
         }
         tags[i] = (uint8_t)t;
+        if (t == kTagEmpty && i < limit) tail = i + 1;
     }
-    for (int off = 32; off > 0; off >>= 1) occ += __shfl_down(occ, off);
-    if ((threadIdx.x & 63) == 0 && occ) atomicAdd(occupied, occ);
+    for (int off = 32; off > 0; off >>= 1) {
+        occ += __shfl_down(occ, off);
+        const unsigned long long o = __shfl_down(tail, off);
+        tail = o > tail ? o : tail;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (occ) atomicAdd(occupied, occ);
+        if (tail) atomicMax(occupied + 1, tail);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Home index ("qidx"): 16 bits per slot h, built once per table, that answer "is the k-mer (quotient q, home slot h)
+// in the table?" without walking anything.  A query can only match a key whose OWN home slot is h (slot = value %
+// numSigs, KGJ:969), and under the reference's lookup (KGJ:944-1034: from the home slot forward, over occupied slots,
+// to the k-mer, the first empty slot or the end of the stream; never wrap) such a key is found iff it lies in the
+// occupied run that starts at h.  value = q * numSigs + h, so among the keys homed at h the quotient identifies the
+// key.  The word holds q % 31 (5 bits each, 31 = none) of the first three distinct keys of that run whose home
+// is h, and bit 15 = "there are more, or the run was not walked to its end": then, and only then, a query whose
+// quotient is not listed has to be walked the long way (a candidate flagged kWalkOn).  When every quotient is below
+// 31, i.e. numSigs > 20^8 / 31 (the KmerGuts table: 1.4e9 slots, quotients 0..18), the word is EXACT: listed = in the
+// table for certain (kScanOn), not listed and no "more" bit = not in the table for certain; P(more than three keys
+// share a home slot) is 0.2 % at load 0.5.  For smaller tables the 5 bits are a hash of the quotient: "not listed" is
+// still a certain miss, "listed" is a candidate that the generic walk checks (kWalkOn) -- same kernels, so that the
+// small tables of the tests and the fuzz run through them.  Negative keys are occupied and match nothing; a key stored
+// in front of its home slot or behind a hole is not reachable and not listed -- exactly the reference's lookup on
+// hand-made tables too.
+constexpr uint32_t kQidxNone = 0x7FFFu;
+constexpr uint32_t kQidxMaxWalk = 1024;        // slots walked per home slot before giving up with the "more" bit
+
+__global__ void build_qidx_kernel(const uint8_t *entries, const uint8_t *tags, uint64_t limit, uint64_t n_idx, uint64_t num_sigs,
+                                  uint64_t magic, uint16_t *idx)
+{
+    TableView tab;
+    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic; tab.m35 = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n_idx; h += stride) {
+        uint32_t w = kQidxNone;
+        if (h < limit && tags[h] != kTagEmpty) {
+            uint32_t n = 0;
+            bool more = false;
+            uint64_t j = h;
+            for (; j < limit && j - h < kQidxMaxWalk; j++) {
+                if (tags[j] == kTagEmpty) break;
+                const uint2 a = *reinterpret_cast<const uint2 *>(entries + j * 24);
+                const int64_t key = (int64_t)(((uint64_t)a.y << 32) | a.x);
+                if (key < 0) continue;                      // occupied, matches no query (KGJ:1000-1004)
+                uint64_t q;
+                if (split_value((uint64_t)key, tab, &q) != h) continue;
+                const uint32_t q5 = (uint32_t)(q % 31u);
+                if ((w & 31u) == q5 || ((w >> 5) & 31u) == q5 || ((w >> 10) & 31u) == q5) continue;   // a duplicate: the first one wins
+                if (n == 3) { more = true; break; }
+                w = (w & ~(31u << (5 * n))) | (q5 << (5 * n));
+                n++;
+            }
+            if (j < limit && j - h >= kQidxMaxWalk) more = true;
+            if (more) w |= 0x8000u;
+        }
+        idx[h] = (uint16_t)w;
+    }
 }
 
 }  // namespace kg

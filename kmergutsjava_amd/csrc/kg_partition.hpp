@@ -517,6 +517,8 @@ __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, 
 // v_mad_u64_u32 runs at a quarter of the VALU rate and the tag pass would pay it in every batch that has a candidate)
 struct CandRec { uint32_t home, quo, id, walked; };   // walked: slots from the home slot; kWalkOn: no record to check yet
 constexpr uint32_t kWalkOn = 0x80000000u;
+constexpr uint32_t kScanOn = 0x40000000u;   // the key is known to lie in the run that starts at home (home index): scan the records
+constexpr uint32_t kWalkedMask = 0x3FFFFFFFu;
 static_assert(sizeof(CandRec) == 16, "CandRec must be 16 bytes");
 
 // reserve `total` (<= kUChunk) consecutive records of a chunked list for this wave; ~0 when the list is full
@@ -696,11 +698,30 @@ __global__ __launch_bounds__(256) void verify_kernel(
             if (act) r = cand[(uint64_t)c * kUChunk + k0 + lane];
             const uint64_t quo = r.quo, home = r.home;
             const uint64_t val = quo * num_sigs + home;
-            uint64_t s = home + (r.walked & ~kWalkOn);
+            uint64_t s = home + (r.walked & kWalkedMask);
             bool found = false;
             Entry e;
             e.key = 0; e.oI = e.avg = e.fI = 0; e.wt = 0.f;
-            if (act) {
+            if (act && (r.walked & kScanOn)) {
+                // listed in the home index: the key is in the occupied run from its home slot; the first record that
+                // carries it is the one the reference finds (KGJ:1003-1015)
+                // (three keys are requested together: a key sits 0.5 slots behind its home slot on average at load 0.5, and
+                //  the slowest lane of the wave sets the pace; records of neighbouring slots share their 128-byte line)
+                for (;;) {
+                    if (s >= limit) { s = limit; ran_off = true; break; }      // (only if the table changed under the index)
+                    const uint64_t s1 = s + 1 < limit ? s + 1 : s, s2 = s + 2 < limit ? s + 2 : s;
+                    const uint2 k0 = *reinterpret_cast<const uint2 *>(tab.entries + s * 24);
+                    const uint2 k1 = *reinterpret_cast<const uint2 *>(tab.entries + s1 * 24);
+                    const uint2 k2 = *reinterpret_cast<const uint2 *>(tab.entries + s2 * 24);
+                    const uint32_t vlo = (uint32_t)val, vhi = (uint32_t)(val >> 32);
+                    if (k0.x == vlo && k0.y == vhi) found = true;
+                    else if (s + 1 < limit && k1.x == vlo && k1.y == vhi) { found = true; s += 1; }
+                    else if (s + 2 < limit && k2.x == vlo && k2.y == vhi) { found = true; s += 2; }
+                    if (found) { e = load_entry(tab, s); break; }
+                    s += 3;
+                }
+                if (COUNTERS) ctr_slots += (s < limit ? s + 1 : limit) - home;
+            } else if (act) {
                 if (!(r.walked & kWalkOn)) {               // a fingerprint match at s: check the record
                     e = load_entry(tab, s);
                     found = e.key == (int64_t)val;

@@ -26,8 +26,14 @@
 
 namespace kg {
 
-constexpr uint32_t kSubThreads = 512;       // K1 workgroup: 8 waves
-constexpr uint32_t kSubSlabs = 8;           // entries per thread and tile
+#ifndef KG_SUB_THREADS
+#define KG_SUB_THREADS 512
+#endif
+#ifndef KG_SUB_SLABS
+#define KG_SUB_SLABS 8
+#endif
+constexpr uint32_t kSubThreads = KG_SUB_THREADS;   // K1 workgroup: 8 waves
+constexpr uint32_t kSubSlabs = KG_SUB_SLABS;       // entries per thread and tile
 constexpr uint32_t kSubTile = kSubThreads * kSubSlabs;
 constexpr uint32_t kMaxSub = 64;            // sub-buckets per bucket (one lane each in the reservation step)
 
@@ -58,19 +64,18 @@ __global__ __launch_bounds__(kSubThreads) void sub_scatter_kernel(
         // the item's entries as slabs of kSubThreads consecutive slots of one region; a tile = up to kSubSlabs slabs
         uint32_t w = w_lo, o = 0;                          // next slab: region w, slots [o, o + kSubThreads)   (uniform)
         uint32_t f = w < w_hi ? min(fill[(uint64_t)b * n_regions + w], cap) : 0u;
-        while (w < w_hi) {
-            uint64_t e[kSubSlabs];
-            uint32_t dr[kSubSlabs];                        // digit << 16 | rank inside the digit (ranks < kSubTile)
+        uint64_t en[kSubSlabs];
+        auto load_tile = [&]() {
 #pragma unroll
             for (uint32_t k = 0; k < kSubSlabs; k++) {
-                e[k] = kEntInvalid;
+                en[k] = kEntInvalid;
                 while (w < w_hi && o >= f) {               // next region with entries left (uniform)
                     w++; o = 0;
                     f = w < w_hi ? min(fill[(uint64_t)b * n_regions + w], cap) : 0u;
                 }
                 if (w < w_hi) {
                     const uint32_t i = o + tid;
-                    if (i < f) e[k] = __builtin_nontemporal_load(ent + ((uint64_t)b * n_regions + w) * cap + i);
+                    if (i < f) en[k] = __builtin_nontemporal_load(ent + ((uint64_t)b * n_regions + w) * cap + i);
                     o += kSubThreads;
                 }
             }
@@ -78,6 +83,15 @@ __global__ __launch_bounds__(kSubThreads) void sub_scatter_kernel(
                 w++; o = 0;
                 f = w < w_hi ? min(fill[(uint64_t)b * n_regions + w], cap) : 0u;
             }
+        };
+        bool have = w < w_hi;
+        if (have) load_tile();
+        while (have) {
+            uint64_t e[kSubSlabs];
+            uint32_t dr[kSubSlabs];                        // digit << 16 | rank inside the digit (ranks < kSubTile)
+#pragma unroll
+            for (uint32_t k = 0; k < kSubSlabs; k++) e[k] = en[k];
+            have = w < w_hi;
 #pragma unroll
             for (uint32_t k = 0; k < kSubSlabs; k++) {
                 dr[k] = 0;
@@ -87,22 +101,24 @@ __global__ __launch_bounds__(kSubThreads) void sub_scatter_kernel(
                 }
             }
             __syncthreads();
-            // one wave: exclusive scan of the tile's histogram (LDS offsets), one global atomic per non-empty sub-bucket
+            // one wave: exclusive scan of the tile's histogram (LDS offsets), one global atomic per non-empty sub-bucket; the
+            // atomics' round trip to the memory side runs while the tile is put in order in LDS
+            uint32_t c_mine = 0, g_mine = 0;
             if (wave == 0) {
-                const uint32_t c = lane < n_sub ? hist[lane] : 0u;
-                uint32_t incl = c;
+                c_mine = lane < n_sub ? hist[lane] : 0u;
+                uint32_t incl = c_mine;
                 for (int off = 1; off < 64; off <<= 1) {
                     const uint32_t y = __shfl_up(incl, off);
                     if ((int)lane >= off) incl += y;
                 }
-                uint32_t g = 0;
-                if (c) g = atomicAdd(&cur2[(uint64_t)b * n_sub + lane], c);
-                if (lane < kMaxSub) { cnt[lane] = c; sbase[lane] = incl - c; gbase[lane] = g; hist[lane] = 0; }
+                if (c_mine) g_mine = atomicAdd(&cur2[(uint64_t)b * n_sub + lane], c_mine);
+                cnt[lane] = c_mine; sbase[lane] = incl - c_mine; hist[lane] = 0;
             }
             __syncthreads();
 #pragma unroll
             for (uint32_t k = 0; k < kSubSlabs; k++)
                 if (e[k] != kEntInvalid) stage[sbase[dr[k] >> 16] + (dr[k] & 0xFFFFu)] = e[k];
+            if (wave == 0) gbase[lane] = g_mine;
             __syncthreads();
             // runs out: wave v takes the sub-buckets d = v, v + 8, ...; consecutive lanes, consecutive entries
             for (uint32_t d = wave; d < n_sub; d += kSubThreads / 64u) {
@@ -126,6 +142,9 @@ __global__ __launch_bounds__(kSubThreads) void sub_scatter_kernel(
                 }
             }
             // (the next tile's LDS writes to stage[] come after two more barriers)
+            // (requesting the next tile before this one is ranked gained nothing alone -- 5.76 against 5.83 ms per Gbp -- and
+            //  cost 0.7 ms of the stage beside the scatter pass of the next chunk: profiles/r03_two_level.md)
+            if (have) load_tile();
         }
     }
 }
@@ -255,6 +274,114 @@ __global__ __launch_bounds__(kProbe2Threads) void sub_probe_kernel(
         for (int off = 32; off > 0; off >>= 1) ctr_slots += __shfl_down(ctr_slots, off);
         if (lane == 0) atomicAdd(&ctr[1], ctr_slots);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2 on the home index (kg_device.hpp, build_qidx_kernel): the sub-bucket's 16-bit words -> LDS (2 bytes per slot), then
+// per entry ONE aligned 2-byte LDS read and a compare of its quotient with the three listed ones: a match is a hit for
+// certain when the index is exact (candidate flagged kScanOn: the verify pass scans the records from the home slot and takes
+// the payload; a hashed index sends it through the generic walk instead), no match with the "more" bit clear is a miss for
+// certain -- nothing is walked and no fingerprint is computed.  The "more" bit (0.2 %
+// of the home slots) falls back to the generic walk (kWalkOn).  lookup_ran_off: a miss whose home slot lies in the
+// occupied run that ends at the end of the record stream (home >= tail_start) is a walk that the reference ends with
+// an EOFException (KGJ:799-802).  Item it, tile and entries as in sub_probe_kernel; dynamic LDS: 2 << sshift bytes.
+__global__ __launch_bounds__(kProbe2Threads) void sub_index_kernel(
+    const uint16_t *__restrict__ qidx, uint64_t n_idx, uint32_t exact /* every quotient < 31 */, uint32_t tail_start,
+    const uint64_t *__restrict__ ent2,
+    const uint32_t *__restrict__ cur2, uint32_t cap2, uint32_t n_items, uint32_t shift, uint32_t sshift, uint32_t *next_item /* zeroed */,
+    CandRec *__restrict__ cand, uint32_t *__restrict__ cand_used, unsigned long long *cand_cursor, uint64_t cand_cap,
+    unsigned long long *ctr)
+{
+    constexpr int N = kProbeN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+    __shared__ uint32_t s_item;
+    const uint16_t *tile16 = reinterpret_cast<const uint16_t *>(tile);
+    const uint32_t tid = threadIdx.x;
+    const int lane = (int)(tid & 63u);
+    const uint32_t tile_slots = 1u << sshift;
+    bool ran_off = false;
+    UListState u;
+    u.base = 0; u.used = kUChunk; u.have = false;      // "full": the first append takes a chunk
+    for (;;) {
+        __syncthreads();                                // the previous item's probes have read the tile
+        if (tid == 0) s_item = atomicAdd(next_item, 1u);
+        __syncthreads();
+        const uint32_t it = s_item;
+        if (it >= n_items) break;
+        const uint32_t n = min(cur2[it], cap2);
+        if (n == 0) continue;                           // (uniform)
+        const uint64_t t0 = (uint64_t)it << sshift;     // first slot of the sub-bucket
+        const uint32_t b = it >> (shift - sshift);
+        const uint64_t *src = ent2 + (uint64_t)it * cap2;
+        uint64_t ev[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const uint32_t i = (uint32_t)k * kProbe2Threads + tid;
+            ev[k] = i < n ? __builtin_nontemporal_load(src + i) : kEntInvalid;
+        }
+        for (uint32_t c = tid * 8u; c < tile_slots; c += kProbe2Threads * 8u) {      // eight words = 16 bytes per load
+            uint4 v = make_uint4(0x7FFF7FFFu, 0x7FFF7FFFu, 0x7FFF7FFFu, 0x7FFF7FFFu);  // behind the index: no key
+            const uint64_t at = t0 + c;
+            if (at + 8u <= n_idx) v = *reinterpret_cast<const uint4 *>(qidx + at);
+            *reinterpret_cast<uint4 *>(tile + 2u * c) = v;
+        }
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < n; c0 += kProbe2Threads * N) {
+            uint64_t en[N];                             // the next batch, requested before this one is probed
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const uint32_t i = c0 + kProbe2Threads * N + (uint32_t)k * kProbe2Threads + tid;
+                en[k] = i < n ? __builtin_nontemporal_load(src + i) : kEntInvalid;
+            }
+            uint32_t home[N], quo[N], candm = 0, walkm = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const uint64_t e = ev[k];
+                const uint32_t low = (uint32_t)e;
+                home[k] = (b << shift) | (low & ((1u << shift) - 1u));       // numSigs < 2^31 on this path
+                quo[k] = low >> shift;
+                if (e != kEntInvalid) {
+                    const uint32_t w = tile16[low & (tile_slots - 1u)];
+                    // a 5-bit field of x is zero iff that listed quotient is the query's; (x - 0x0421) & ~x & 0x4210 is non-zero
+                    // iff some field is zero (a borrow can only reach a field above a zero one)
+                    const uint32_t q5 = exact ? quo[k] : quo[k] % 31u;
+                    const uint32_t x = (w & 0x7FFFu) ^ __umul24(q5, 0x0421u);
+                    const bool match = (((x - 0x0421u) & ~x) & 0x4210u) != 0u;
+                    const bool more = (w & 0x8000u) != 0u;
+                    if (match) candm |= 1u << k;
+                    else if (more) { candm |= 1u << k; walkm |= 1u << k; }
+                    else if (home[k] >= tail_start) ran_off = true;
+                }
+            }
+            uint32_t cn[N], rank[N], total = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const unsigned long long m = __ballot((candm >> k) & 1u);
+                cn[k] = (uint32_t)__popcll(m);
+                rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                total += cn[k];
+            }
+            if (total) {
+                unsigned long long at = chunk_reserve(u, total, cand_used, cand_cursor, cand_cap, lane);
+                if (at != ~0ull) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        if ((candm >> k) & 1u) {
+                            CandRec cr;
+                            cr.home = home[k]; cr.quo = quo[k];
+                            cr.id = (uint32_t)(ev[k] >> 32); cr.walked = (((walkm >> k) & 1u) || !exact) ? kWalkOn : kScanOn;
+                            cand[at + rank[k]] = cr;
+                        }
+                        at += cn[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < N; k++) ev[k] = en[k];
+        }
+    }
+    chunk_finish(u, cand_used, cand_cap, lane);
+    flush_ran_off(ran_off, ctr, lane);
 }
 
 }  // namespace kg

@@ -91,6 +91,13 @@ struct DevCache {
         free_.emplace(it->second, p);
         live.erase(it);
     }
+    size_t live_bytes()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t n = 0;
+        for (auto &kv : live) n += kv.second;
+        return n;
+    }
     void release_all()
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -173,6 +180,10 @@ struct kg_table {
     bool own_entries = false;
     uint8_t *d_entries = nullptr;
     uint8_t *d_tags = nullptr;
+    uint16_t *d_qidx = nullptr;         // home index (kg_device.hpp, build_qidx_kernel) or null when the table is not eligible
+    uint64_t n_qidx = 0;                // its length in words (limit rounded up, filled with "no key")
+    bool qidx_exact = false;            // every quotient < 31: a listed quotient is a hit for certain
+    uint64_t tail_start = 0;            // first slot of the occupied run that ends at the end of the record stream
     int64_t num_sigs = 0, entry_size = 0, version = 0;
     uint64_t limit = 0;          // complete 24-byte records present
     uint64_t magic = 0;          // floor(2^64 / num_sigs)
@@ -180,11 +191,13 @@ struct kg_table {
     uint64_t occupied = 0;
     double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
     size_t scatter_lds[2] = {0, 0};  // dynamic LDS the scatter kernel (DNA / protein) has been allowed so far
-    size_t probe2_lds[2] = {0, 0};   // ... and the second-level probe kernel (without / with counters)
+    size_t probe2_lds[3] = {0, 0, 0};   // ... and the second-level probe kernels (tags without / with counters, home index)
     hipEvent_t ev[8] = {};
     // Pinned host words for the few counters a scan reads back (a hipMemcpyAsync to pageable memory blocks the host per
     // copy; to pinned memory it does not): [0..47] d_pc, [48..79] d_ovfc (as 64 x u32), [80..87] d_totals, [88] CALL total
     uint64_t *h_pin = nullptr;
+    std::atomic<int> busy{0};    // a kg_scan* is in flight on this table (its streams, events and pinned words are per table)
+    uint32_t fail_alloc_at = 0, alloc_count = 0;   // test hook KG_TEST_FAIL_ALLOC (include/kmerguts_hip.h)
     DevCache cache;
     PinCache pins;
 };
@@ -219,6 +232,8 @@ uint32_t env_u32(const char *name, uint32_t dflt)
 
 int dalloc(kg_table *t, void **p, size_t bytes)
 {
+    if (t->fail_alloc_at && ++t->alloc_count == t->fail_alloc_at)
+        return fail(KG_ERR_NOMEM, "device allocation failed: KG_TEST_FAIL_ALLOC test hook");
     hipError_t e = t->cache.get(p, bytes);
     if (e != hipSuccess) return fail(KG_ERR_NOMEM, std::string("device allocation failed: ") + hipGetErrorString(e));
     return KG_OK;
@@ -244,18 +259,30 @@ int table_finish(kg_table *t)
     uint64_t n_tags = t->limit + kg::kTagPad;
     HIP_TRY(hipMalloc((void **)&t->d_tags, n_tags));
     unsigned long long *d_occ = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_occ, 8));
-    HIP_TRY(hipMemsetAsync(d_occ, 0, 8, t->stream));
+    HIP_TRY(hipMalloc((void **)&d_occ, 16));
+    HIP_TRY(hipMemsetAsync(d_occ, 0, 16, t->stream));
     uint64_t want = (n_tags + 255) / 256;
     uint32_t grid = (uint32_t)(want < 256ull * 16 ? (want ? want : 1) : 256ull * 16);
     hipLaunchKernelGGL(kg::build_tags_kernel, dim3(grid), dim3(256), 0, t->stream, t->d_entries, t->limit, n_tags,
                        (uint64_t)t->num_sigs, t->magic, t->d_tags, d_occ);
     HIP_TRY(hipGetLastError());
-    unsigned long long occ = 0;
-    HIP_TRY(hipMemcpyAsync(&occ, d_occ, 8, hipMemcpyDeviceToHost, t->stream));
+    // the home index: 2 bytes per slot, for every table the scatter pass applies to (64 <= numSigs < 2^31); exact when every
+    // quotient of a k-mer is below 31 (numSigs > 20^8 / 31).  KG_QIDX=0 leaves it out (the tag kernels serve every table).
+    t->qidx_exact = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1 <= 31;
+    if (t->m35 != 0 && t->limit > 0 && env_u32("KG_QIDX", 1u) != 0) {
+        t->n_qidx = (t->limit + 7) / 8 * 8 + 8;
+        HIP_TRY(hipMalloc((void **)&t->d_qidx, t->n_qidx * 2));
+        const uint64_t wantq = (t->n_qidx + 255) / 256;
+        hipLaunchKernelGGL(kg::build_qidx_kernel, dim3((uint32_t)std::min<uint64_t>(wantq, 256ull * 32)), dim3(256), 0, t->stream,
+                           t->d_entries, t->d_tags, t->limit, t->n_qidx, (uint64_t)t->num_sigs, t->magic, t->d_qidx);
+        HIP_TRY(hipGetLastError());
+    }
+    unsigned long long occ[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(occ, d_occ, 16, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     HIP_TRY(hipFree(d_occ));
-    t->occupied = occ;
+    t->occupied = occ[0];
+    t->tail_start = occ[1];
     for (auto &e : t->pev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&t->stream3, hipStreamNonBlocking));
@@ -522,6 +549,7 @@ void kg_table_close(kg_table *t)
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     if (t->own_entries && t->d_entries) (void)hipFree(t->d_entries);
     if (t->d_tags) (void)hipFree(t->d_tags);
+    if (t->d_qidx) (void)hipFree(t->d_qidx);
     t->cache.release_all();
     t->pins.release_all();
     if (t->h_pin) (void)hipHostFree(t->h_pin);
@@ -899,7 +927,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         // slots, and probed against tags held in LDS.  KG_PART_LEVELS: 1 = tag pass out of the L2 (bucket_tag_kernel),
         // 2 = sub-scatter + LDS probe.  KG_PART_SUBSHIFT: log2 of a sub-bucket's slots (tags = LDS bytes per workgroup).
         uint32_t levels = env_u32("KG_PART_LEVELS", 1u);
-        uint32_t sshift = std::min(17u, env_u32("KG_PART_SUBSHIFT", 16u));
+        // with the home index (2 bytes per slot in LDS, no counters kernel) a sub-bucket is at most 2^15 slots
+        const bool use_qidx = levels == 2 && t->d_qidx != nullptr && !counters && env_u32("KG_QIDX", 1u) != 0;
+        uint32_t sshift = std::min(use_qidx ? 15u : 17u, env_u32("KG_PART_SUBSHIFT", use_qidx ? 15u : 16u));
         if (sshift + 6 < part_shift) sshift = part_shift - 6;                         // at most kMaxSub sub-buckets per bucket
         if (sshift + 1 > part_shift) sshift = part_shift - 1;
         if (levels != 2 || part_shift < 9 || sshift < 8) levels = 1;
@@ -920,8 +950,13 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             cap2 = std::max(16u, (cap2 + 15u) / 16u * 16u);
             if ((rc = sc.get(&d_ent2, (size_t)(n_sub_total * cap2 * n_chunks_p)))) return rc;
             if ((rc = sc.get(&d_cur2, (size_t)(n_sub_total * n_chunks_p)))) return rc;
-            const size_t tile_lds = ((size_t)1 << sshift) + 16;
-            if (t->probe2_lds[counters ? 1 : 0] < tile_lds) {
+            const size_t tile_lds = use_qidx ? ((size_t)2 << sshift) : ((size_t)1 << sshift) + 16;
+            if (use_qidx) {
+                if (t->probe2_lds[2] < tile_lds) {
+                    HIP_TRY(hipFuncSetAttribute((const void *)kg::sub_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+                    t->probe2_lds[2] = tile_lds;
+                }
+            } else if (t->probe2_lds[counters ? 1 : 0] < tile_lds) {
                 if (counters) HIP_TRY(hipFuncSetAttribute((const void *)kg::sub_probe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
                 else HIP_TRY(hipFuncSetAttribute((const void *)kg::sub_probe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
                 t->probe2_lds[counters ? 1 : 0] = tile_lds;
@@ -947,6 +982,13 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         kg_hit *d_ulist = nullptr;
         uint32_t *d_cused = nullptr, *d_candused = nullptr;
         kg::CandRec *d_cand = nullptr;
+        // whatever way this block is left (an error return in the middle of an attempt included), the list blocks go
+        // back to the cache with the rest of the scratch once the streams are idle (Scratch's destructor runs later)
+        struct ListGuard {
+            Scratch &sc;
+            void **slot[4];
+            ~ListGuard() { for (void **q : slot) if (*q) { sc.adopt(*q); *q = nullptr; } }
+        } list_guard{sc, {(void **)&d_ulist, (void **)&d_cused, (void **)&d_cand, (void **)&d_candused}};
         bool too_skewed = false;
         const uint32_t grab_unit = 256u * kg::kProbeN;
         const uint32_t probe_grab = (std::max(env_u32("KG_PROBE_GRAB", cap), grab_unit) + grab_unit - 1) / grab_unit * grab_unit;
@@ -957,9 +999,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             const size_t cused_stride = (size_t)(ucap / kg::kUChunk + 1), candused_stride = (size_t)(ccap / kg::kUChunk + 1);
             if ((rc = dalloc(t, (void **)&res->d_hits, hits_cap * sizeof(kg_hit)))) return rc;
             if ((rc = dalloc(t, (void **)&d_ulist, ucap * n_chunks_p * sizeof(kg_hit)))) return rc;
-            if ((rc = dalloc(t, (void **)&d_cused, cused_stride * n_chunks_p * 4))) { sc.adopt(d_ulist); return rc; }
-            if ((rc = dalloc(t, (void **)&d_cand, ccap * n_chunks_p * sizeof(kg::CandRec)))) { sc.adopt(d_ulist); sc.adopt(d_cused); return rc; }
-            if ((rc = dalloc(t, (void **)&d_candused, candused_stride * n_chunks_p * 4))) { sc.adopt(d_ulist); sc.adopt(d_cused); sc.adopt(d_cand); return rc; }
+            if ((rc = dalloc(t, (void **)&d_cused, cused_stride * n_chunks_p * 4))) return rc;
+            if ((rc = dalloc(t, (void **)&d_cand, ccap * n_chunks_p * sizeof(kg::CandRec)))) return rc;
+            if ((rc = dalloc(t, (void **)&d_candused, candused_stride * n_chunks_p * 4))) return rc;
             {   // one launch for all clears (d_totals: totals, counters and flags of a re-run start over)
                 kg::ClearList cl;
                 cl.n = 7;
@@ -1019,11 +1061,15 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                     hipLaunchKernelGGL(kg::sub_scatter_kernel, dim3(grid1), dim3(kg::kSubThreads), 0, s2, ent_c, fill_c, n_wg, cap,
                                        part_buckets, part_shift, sshift, rpi, next_c, ent2_c, cur2_c, cap2, ovfc_c, ovf_cap,
                                        ovf_bucket_c, ovf_ent_c);
-                    const size_t tile_lds = ((size_t)1 << sshift) + 16;
+                    const size_t tile_lds = use_qidx ? ((size_t)2 << sshift) : ((size_t)1 << sshift) + 16;
                     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / (tile_lds + 256)));
                     const uint32_t grid2 = std::min(n_items2, std::max(1u, env_u32("KG_PROBE2_GRID", 256u * per_cu)));
 #define KG_TAG2_ARGS t->d_tags, t->limit, ent2_c, cur2_c, cap2, n_items2, part_shift, sshift, next_c + 64, cand_c, candused_c, ccur_c, ccap, d_ctr
-                    if (counters) hipLaunchKernelGGL((kg::sub_probe_kernel<true>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
+                    if (use_qidx)
+                        hipLaunchKernelGGL(kg::sub_index_kernel, dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, t->d_qidx, t->n_qidx,
+                                           t->qidx_exact ? 1u : 0u, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent2_c, cur2_c, cap2, n_items2, part_shift,
+                                           sshift, next_c + 64, cand_c, candused_c, ccur_c, ccap, d_ctr);
+                    else if (counters) hipLaunchKernelGGL((kg::sub_probe_kernel<true>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
                     else hipLaunchKernelGGL((kg::sub_probe_kernel<false>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
 #undef KG_TAG2_ARGS
                 } else if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
@@ -1084,10 +1130,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             if (getenv("KG_DEBUG"))
                 fprintf(stderr, "[kg] partition attempt %d: %u chunks (largest %llu of %llu blocks), overflow groups <= %u (cap %u), hit list <= %llu "
                                 "(cap %llu), candidates <= %llu (cap %llu), regions/chunk %llu x %u entries, %u buckets, shift %u, %u scatter "
-                                "workgroups, hits %llu, levels %u (sub-bucket shift %u, %u entries each)\n",
+                                "workgroups, hits %llu, levels %u%s (sub-bucket shift %u, %u entries each)\n",
                         attempt, n_chunks_p, (unsigned long long)max_chunk, (unsigned long long)nblocks, max_ovf, ovf_cap,
                         (unsigned long long)need_u, (unsigned long long)ucap, (unsigned long long)need_c, (unsigned long long)ccap,
-                        (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg, (unsigned long long)h_pc[16 + n_chunks_p], levels, sshift, cap2);
+                        (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg, (unsigned long long)h_pc[16 + n_chunks_p], levels, use_qidx ? " + home index" : "", sshift, cap2);
             if (guard) { too_skewed = true; st.fallback = 2; break; }    // the scatter pass's spin guard fired: direct path
             if (max_ovf > ovf_cap) { too_skewed = true; st.fallback = 1; break; }   // more overflow than provisioned: direct path
             n_hits = h_pc[16 + n_chunks_p];
@@ -1100,8 +1146,6 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             if (need_c > ccap) { ccap = (need_c + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk; ucap = std::max(ucap, ccap); }   // hits <= candidates
             else ucap = (need_u + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         }
-        sc.adopt(d_cand); sc.adopt(d_candused);
-        sc.adopt(d_ulist); sc.adopt(d_cused);
         if (too_skewed) {
             dfree(t, res->d_hits);
             res->d_hits = nullptr;
@@ -1117,7 +1161,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             part_done = true;
             st.partitioned = 1;
             st.part_chunks = (int32_t)n_chunks_p; st.part_buckets = (int32_t)part_buckets; st.part_shift = (int32_t)part_shift;
-            st.part_levels = (int32_t)levels;
+            st.part_levels = (int32_t)(levels == 2 && use_qidx ? 3 : levels);
         }
     }
     if (!part_done) {
@@ -1135,6 +1179,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
     if (stage_cap > 0xFFFFFF00ull) stage_cap = 0xFFFFFF00ull;
     if (env_u32("KG_TEST_TINY_LISTS", 0u)) stage_cap = 256;                    // tests: force the resize-and-rerun path
     kg_hit *d_stage = nullptr;
+    struct StageGuard { Scratch &sc; kg_hit *&p; ~StageGuard() { if (p) sc.adopt(p); } } stage_guard{sc, d_stage};
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = dalloc(t, (void **)&d_stage, stage_cap * sizeof(kg_hit)))) return rc;
         unsigned long long *d_cursor = (unsigned long long *)(d_totals + 1);
@@ -1166,7 +1211,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         }
         HIP_TRY(hipEventRecord(t->ev[2], t->stream));
         st.scan_launches++;
-        if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) { sc.adopt(d_stage); return rc; }
+        if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) return rc;
         uint64_t h_tot[6] = {0, 0, 0, 0, 0, 0};
         HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 48, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
@@ -1187,7 +1232,6 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
     st.n_hits = (int64_t)n_hits;
 
     // ---- ordered placement ----
-    sc.adopt(d_stage);
     if ((rc = dalloc(t, (void **)&res->d_hits, n_hits * sizeof(kg_hit)))) return rc;
     if (nblocks) {
         uint32_t grid = (uint32_t)((nblocks + kg::kWavesPerWG - 1) / kg::kWavesPerWG);
@@ -1230,6 +1274,14 @@ int scan_entry(kg_table *t, const kg_params *p, const uint8_t *seq, bool on_devi
     if (n_seqs > 0x7FFFFFF0ll / 6) return fail(KG_ERR_LIMIT, "too many sequences in one batch");
     if (p->min_hits < 2)
         return fail(KG_ERR_UNSUPPORTED, "minHits < 2: the reference throws in processSetOfHits (KGJ:442); refusing");
+    // One scan at a time per table: the streams, events, pinned counter words and the block cache's "freed when the
+    // stream is idle" rule are per table.  A second thread is turned away instead of corrupting them.
+    if (t->busy.exchange(1) != 0)
+        return fail(KG_ERR_BUSY, "another kg_scan* is in flight on this kg_table (one scan at a time per table; open a second table "
+                                 "object for concurrent scans)");
+    struct BusyGuard { kg_table *t; ~BusyGuard() { t->busy.store(0); } } busy_guard{t};
+    t->fail_alloc_at = env_u32("KG_TEST_FAIL_ALLOC", 0u);
+    t->alloc_count = 0;
     HIP_TRY(hipSetDevice(t->device));
     int64_t total = offsets[n_seqs] - offsets[0];
     if (total < 0) return fail(KG_ERR_ARG, "offsets must be non-decreasing");
@@ -1471,6 +1523,11 @@ int kg_result_copy_hits(kg_result *r, int64_t first, int64_t count, kg_hit *dst)
     (void)hipStreamSynchronize(s);
     r->tab->pins.put(stage[0]); r->tab->pins.put(stage[1]);
     return rc;
+}
+
+int64_t kg_table_live_device_bytes(kg_table *t)
+{
+    return t ? (int64_t)t->cache.live_bytes() : 0;
 }
 
 const void *kg_result_device_hits(const kg_result *r) { return r ? r->d_hits : nullptr; }

@@ -236,6 +236,10 @@ class SignatureTable:
         N.check(N.load().kg_table_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return {"numSigs": a.value, "entrySize": b.value, "version": c.value, "occupied": d.value}
 
+    def live_device_bytes(self) -> int:
+        """Device bytes of scratch / result blocks handed out by the table's block cache and not yet returned."""
+        return int(N.load().kg_table_live_device_bytes(self._h))
+
     def scan(self, seq, offsets, params: Optional[Params] = None, device_ptr: Optional[int] = None) -> ScanResult:
         """seq: bytes / uint8 ndarray with the concatenated raw sequence characters, or None when
         device_ptr gives their address in HBM.  offsets: int64[n_seqs + 1]."""

@@ -41,12 +41,15 @@ def main():
                         assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s %s" % (seed, w["it"], mode, w["env"], w["env2"] if mode == "2" else ""))
                         assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
                         n_part += r.stats["partitioned"]
+                    if mode == "2":                        # the home-index kernel (no KG_F_COUNTERS variant)
+                        with tab.scan(w["raw"], w["off"], hotpath.Params(**p)) as r:
+                            assert_same_records(r, ora, "fuzz seed %d it %d home index %s %s" % (seed, w["it"], w["env"], w["env2"]))
             done += 1
             calls += len(ora["calls"])
             hits += len(ora["hits"])
             if done >= n:
                 break
-    print(json.dumps({"workloads": done, "scans": 3 * done, "ran_partitioned": n_part, "oracle_hits": hits, "oracle_calls": calls,
+    print(json.dumps({"workloads": done, "scans": 4 * done, "ran_partitioned": n_part, "oracle_hits": hits, "oracle_calls": calls,
                       "all_identical": True}))
 
 

@@ -216,6 +216,32 @@ def test_K15_otu_buffer_persists_across_frames(oracle):
     assert txt.endswith("OTU-COUNTS\tc1[%d]\t5-4\t5-3\n" % len(contig))
 
 
+def test_K16_to_K19_aggregation_cases(oracle):
+    """tests/kat_cases.py: -O at |d| = 20 / 21, Math.abs(Integer.MIN_VALUE), the 39 998 cap with the pair rule firing on a
+    hit that was not appended, int wrap in the gap test -- expected values derived by hand there."""
+    import kat_cases as K
+    for make in K.AGGREGATION_CASES:
+        for name, h, kw, want_calls, want_otu in make():
+            c, o = both(oracle, h, **kw)
+            assert c == want_calls, (name, c)
+            assert o == want_otu, (name, o)
+
+
+def test_K20_K21_lookup_cases(oracle):
+    """tests/kat_cases.py: a negative whichKmer inside a probe cluster, a table file with more records than numSigs."""
+    import kat_cases as K
+    for make in K.LOOKUP_CASES:
+        for name, img, q, want in make():
+            for mode in (0, 1):
+                r = oracle.run(img, q, np.array([0, len(q)]), aa=True, lookup_mode=mode, min_hits=2)
+                got = [(int(h["from0InProt"]), int(h["oI"]), int(h["avgOffFromEnd"]), int(h["fI"]), float(h["functionWt"]))
+                       for h in r["hits"]]
+                assert got == want, (name, mode, got)
+            m = M.Model(aa=True, min_hits=2)                 # the independent Python restatement, literal merge-join
+            m.run(img, ["f%d" % i for i in range(16)], ">q\n" + q.decode() + "\n")
+            assert [tuple(h[1:]) for h in m.hits] == want, (name, m.hits)
+
+
 def test_java_format_f(oracle):
     """N3: HALF_UP on exact ties (C's printf would give 5.007812)."""
     cases = [(5.0078125, 6, "5.007813"), (0.5, 6, "0.500000"), (16777216.0, 6, "16777216.000000"), (0.1, 6, "0.100000"),

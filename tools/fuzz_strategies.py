@@ -28,7 +28,11 @@ for w in workloads(iters, seed):
                              st["windows_valid"], st["slots_inspected"], st["residues"])
                 if mode == "1":
                     n_part += st["partitioned"]; n_fallback += 1 - st["partitioned"]
-    same = out["0"] == out["1"] == out["2"]
+            if mode == "2":                                # ... and through the home index (no KG_F_COUNTERS kernel)
+                with tab.scan(w["raw"], w["off"], hotpath.Params(**w["params"])) as r:
+                    out["3"] = (r.hits().tobytes(), r.container_hit_start().tobytes(), r.calls().tobytes(), r.container_call_start().tobytes(),
+                                r.otu().tobytes(), r.hit_events().tobytes(), r.container_tail_events().tobytes()) + out["2"][7:]
+    same = out["0"] == out["1"] == out["2"] == out["3"]
     print(json.dumps({"it": w["it"], "aa": w["aa"], "num_sigs": w["num_sigs"], "load": round(w["load"], 2), "n_seqs": len(w["off"]) - 1,
                       "bp": int(w["off"][-1]), "hits": len(out["0"][0]) // 24, "calls": len(out["0"][2]) // 24, "env": w["env"], "env2": w["env2"], "same": same}), flush=True)
     assert same, "strategies disagree"
