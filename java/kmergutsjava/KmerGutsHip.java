@@ -7,29 +7,33 @@ import com.sun.jna.Structure;
 import com.sun.jna.ptr.IntByReference;
 import com.sun.jna.ptr.PointerByReference;
 
-import java.util.Arrays;
-import java.util.List;
-
 /**
  * JNA binding of libkmerguts_hip.so (C ABI: include/kmerguts_hip.h), the MI355X implementation of the
  * kmer_guts hot path.  jna-3.4.0.jar is already on the reference's classpath (build.xml:27), so a
  * maintainer adds this one file and the call site shown in INTEGRATION.md.
  *
+ * Written against the JNA level the reference ships, 3.4.0: a Structure's field order is given with
+ * setFieldOrder(String[]) in its constructor (the abstract getFieldOrder() only exists from JNA 3.5.0 on),
+ * Native.loadLibrary(String, Class) loads the library.
+ *
  * NOT COMPILED IN THIS REPOSITORY'S BUILD IMAGE (no JDK there); it is kept mechanical on purpose:
- * one Java method per exported C function, structures field for field.
+ * one Java method per exported C function, structures field for field -- tests/test_java_binding.py parses this
+ * file and checks method names, arities and structure fields against include/kmerguts_hip.h.
  */
 public interface KmerGutsHip extends Library {
     KmerGutsHip LIB = (KmerGutsHip) Native.loadLibrary("kmerguts_hip", KmerGutsHip.class);
 
     int KG_OK = 0;
+    int KG_ERR_ARG = -1, KG_ERR_IO = -2, KG_ERR_FORMAT = -3, KG_ERR_DEVICE = -4, KG_ERR_NOMEM = -5, KG_ERR_UNSUPPORTED = -6,
+        KG_ERR_LIMIT = -7, KG_ERR_BUSY = -8;
     int KG_F_COUNTERS = 1;
     int KG_F_SKIP_AGGREGATE = 2;
 
     /** struct kg_params: the instance fields the hot path reads (KmerGutsJava.java:102-106). */
     class KgParams extends Structure {
         public int aa, order_constraint, min_hits, min_weighted_hits, max_gap, flags;
-        @Override protected List<String> getFieldOrder() {
-            return Arrays.asList("aa", "order_constraint", "min_hits", "min_weighted_hits", "max_gap", "flags");
+        public KgParams() {
+            setFieldOrder(new String[] {"aa", "order_constraint", "min_hits", "min_weighted_hits", "max_gap", "flags"});
         }
     }
 
@@ -40,11 +44,12 @@ public interface KmerGutsHip extends Library {
         public float ms_scan, ms_order, ms_aggregate, ms_total;
         public int scan_launches, partitioned;
         public float ms_part_scatter, ms_part_tag, ms_part_verify;
-        public int fallback, part_chunks, part_buckets, part_shift, lookup_ran_off, agg_pieces, reserved0;
-        @Override protected List<String> getFieldOrder() {
-            return Arrays.asList("n_seqs", "n_containers", "n_blocks", "n_hits", "n_calls", "residues", "windows",
+        public int fallback, part_chunks, part_buckets, part_shift, lookup_ran_off, agg_pieces, part_levels;
+        public KgStats() {
+            setFieldOrder(new String[] {"n_seqs", "n_containers", "n_blocks", "n_hits", "n_calls", "residues", "windows",
                     "windows_valid", "slots_inspected", "table_bytes", "ms_scan", "ms_order", "ms_aggregate",
-                    "ms_total", "scan_launches", "partitioned", "ms_part_scatter", "ms_part_tag", "ms_part_verify", "fallback", "part_chunks", "part_buckets", "part_shift", "lookup_ran_off", "agg_pieces", "reserved0");
+                    "ms_total", "scan_launches", "partitioned", "ms_part_scatter", "ms_part_tag", "ms_part_verify", "fallback",
+                    "part_chunks", "part_buckets", "part_shift", "lookup_ran_off", "agg_pieces", "part_levels"});
         }
     }
 
@@ -53,6 +58,7 @@ public interface KmerGutsHip extends Library {
     int kg_table_from_memory(Pointer image, long nbytes, int device, PointerByReference out);
     int kg_table_from_device(Pointer dEntries, long numSigs, int device, PointerByReference out);
     int kg_table_info(Pointer table, long[] numSigs, long[] entrySize, long[] version, long[] occupied);
+    long kg_table_live_device_bytes(Pointer table);
     void kg_table_close(Pointer table);
 
     // replaces prepareQuery/addKmers, the query sort, lookup and gatherHits/processSetOfHits

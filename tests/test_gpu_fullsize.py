@@ -374,3 +374,139 @@ def test_copy_hits_and_zero_copy_views(hp):
         assert r.calls(copy=False).tobytes() == r.calls().tobytes() and r.otu(copy=False).tobytes() == r.otu().tobytes()
         with pytest.raises(Exception):
             r.copy_hits(len(h) - 10, 11)
+
+
+@pytest.mark.parametrize("strategy", ["direct", "partitioned", "partitioned2"])
+def test_config1_plumbing_at_its_stated_size(hp, oracle, strategy, monkeypatch):
+    """BASELINE config 1 as written: 10 000 proteins of ~300 aa against a 1 000 003-slot table holding 500 000 signatures
+    (half of them the sequences' own 8-mers), AA mode, through the whole C ABI: every record against the oracle's literal
+    merge-join, with every scan strategy."""
+    from kmergutsjava_amd import synth
+    from helpers import assert_same_records
+    seq, off, rec, placed = synth.plumbing_config()
+    assert len(off) - 1 == 10000 and rec.shape[0] == 1000003 and 480000 < placed <= 500000
+    img = synth.table_image(rec)
+    sb = seq.numpy().tobytes()
+    monkeypatch.setenv("KG_PARTITION", "0" if strategy == "direct" else "1")
+    monkeypatch.setenv("KG_PART_LEVELS", "2" if strategy == "partitioned2" else "1")
+    with hp.SignatureTable.from_bytes(img) as tab:
+        # the reference's defaults (-m 5 -g 200: functions are random here, so hardly any CALL) and a setting that calls a lot
+        for kw in (dict(), dict(min_hits=2, max_gap=600)):
+            ora = oracle.run(img, sb, off, aa=True, lookup_mode=0, **kw)
+            assert ora["residues"] > 2_900_000 and len(ora["hits"]) > 100_000
+            assert not kw or len(ora["calls"]) > 1000
+            for counters in (True, False):           # (with the second level: the tag kernels / the home-index kernel)
+                with tab.scan(sb, off, hp.Params(aa=True, counters=counters, **kw)) as r:
+                    assert_same_records(r, ora, "config 1 %s counters=%s %s" % (strategy, counters, kw))
+                    if counters:
+                        o1 = oracle.run(img, sb, off, aa=True, lookup_mode=1, **kw)
+                        assert r.stats["windows_valid"] == o1["windows_valid"] and r.stats["slots_inspected"] == o1["slots_inspected"]
+
+
+def test_two_level_scan_and_home_index_at_full_size(hp, oracle, full_table, monkeypatch):
+    """KG_PART_LEVELS=2 on BASELINE config 3: the second partition level with the tags in LDS (KG_F_COUNTERS scans) and with
+    the table's home index in LDS (exact for this table: quotients 0..18) must leave the records of the default
+    one-level scan, compared over the whole result on the device, and the oracle's on contigs from every chunk."""
+    from kmergutsjava_amd import synth
+    dev = torch.device("cuda", 0)
+    tab = full_table["tab"]
+    lens = synth.contig_mix_lengths(1_000_000_000, 301)
+    off = synth.offsets_of(lens)
+    seq = synth.random_dna(int(off[-1]), 302, dev)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("KG_PARTITION", raising=False)
+    monkeypatch.setenv("KG_PART_LEVELS", "1")
+    with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as r1:
+        assert r1.stats["partitioned"] == 1 and r1.stats["part_levels"] == 1
+        monkeypatch.setenv("KG_PART_LEVELS", "2")
+        with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as r3:
+            assert r3.stats["part_levels"] == 3 and r3.stats["fallback"] == 0, r3.stats
+            _same_on_device(r1, r3, "one level vs two levels + home index")
+            assert r3.stats["lookup_ran_off"] == r1.stats["lookup_ran_off"]
+            idx = synth.spread_sample(off, groups=4, per_group=10, max_bp_per_group=1_500_000)
+            _oracle_sample(oracle, full_table["image"](), seq, off, idx, r3, "two levels + home index")
+        with tab.scan(None, off, hp.Params(counters=True), device_ptr=seq.data_ptr()) as r2:
+            assert r2.stats["part_levels"] == 2 and r2.stats["fallback"] == 0, r2.stats
+            _same_on_device(r1, r2, "one level vs two levels (tags in LDS)")
+        monkeypatch.setenv("KG_PART_LEVELS", "1")
+        with tab.scan(None, off, hp.Params(counters=True), device_ptr=seq.data_ptr()) as rc:
+            assert (rc.stats["windows_valid"], rc.stats["slots_inspected"]) == (r2.stats["windows_valid"], r2.stats["slots_inspected"])
+
+
+def test_home_index_on_hand_made_clusters_in_a_full_size_table(hp, oracle, monkeypatch):
+    """The exact home index (numSigs > 20^8 / 31) on the cases it could get wrong, planted by hand into an otherwise
+    empty 900 000 011-slot table and queried as proteins: four and five keys sharing one home slot (the 'more' bit), a key
+    behind a NEGATIVE whichKmer, a key behind a hole (not reachable), a key in front of its home slot (not reachable), the
+    same key twice in one run (the first one wins), and keys in the occupied run that ends at the end of the record stream
+    (lookup_ran_off).  Oracle: literal merge-join and direct probing."""
+    from kmergutsjava_amd import synth
+    import kat_cases as K
+    n = 900_000_011
+    dev = torch.device("cuda", 0)
+    rec = torch.empty((n, 6), dtype=torch.int32, device=dev)
+    empty = 20 ** 8 + 1
+    rec[:, 0] = empty & 0xFFFFFFFF if (empty & 0xFFFFFFFF) < 2 ** 31 else (empty & 0xFFFFFFFF) - 2 ** 32
+    rec[:, 1] = empty >> 32
+    rec[:, 2:] = 0
+
+    def put(slot, key, oi, fi, wt=1.0):
+        lo, hi = key & 0xFFFFFFFF, (key >> 32) & 0xFFFFFFFF
+        row = torch.tensor([lo if lo < 2 ** 31 else lo - 2 ** 32, hi if hi < 2 ** 31 else hi - 2 ** 32, oi, 3, fi,
+                            int(np.float32(wt).view(np.int32))], dtype=torch.int32, device=dev)
+        rec[slot] = row
+
+    queries = []                                   # (k-mer value, expected oI or None)
+    h = 1000                                       # five keys homed at slot 1000: quotients 0..4 -> the fifth sets nothing new, 'more'
+    for q in range(5):
+        put(h + q, q * n + h, 10 + q, 2)
+        queries.append((q * n + h, 10 + q))
+    queries.append((7 * n + h, None))              # same home, unknown quotient: walks the run (more bit), not found
+    h = 5000                                       # negative key at the home slot, the real key behind it
+    put(h, -12345, 1, 1); put(h + 1, 3 * n + h, 21, 2)
+    queries.append((3 * n + h, 21))
+    h = 9000                                       # key behind a hole: slot h occupied by another home's key, h+1 empty, h+2 the key
+    put(h, 2 * n + h - 1 + 1, 1, 1)                # (a key homed at h with quotient 2)
+    put(h + 2, 4 * n + h, 22, 2)
+    queries.append((4 * n + h, None)); queries.append((2 * n + h, 1))
+    h = 13000                                      # key stored in front of its home slot
+    put(h - 1, 5 * n + h, 23, 2)
+    queries.append((5 * n + h, None))
+    h = 17000                                      # the same key twice in one run: the first record's payload
+    put(h, 6 * n + h, 24, 2); put(h + 1, 6 * n + h, 25, 2)
+    queries.append((6 * n + h, 24))
+    h = n - 3                                      # the run that ends with the stream: found ones are found, a miss runs off
+    put(h, 1 * n + h, 26, 2); put(h + 1, 2 * n + h, 27, 2); put(h + 2, 0 * n + h + 2, 28, 2)
+    queries.append((2 * n + h, 27)); queries.append((0 * n + h + 2, 28))
+    run_off_query = (9 * n + h + 1, None)
+    torch.cuda.synchronize()
+    host = torch.empty(24 + n * 24, dtype=torch.uint8)
+    host[:24] = torch.frombuffer(bytearray(struct.pack("<qqq", n, 24, 1)), dtype=torch.uint8)
+    host[24:].view(torch.int32).view(n, 6).copy_(rec)
+    img = host.numpy()
+    monkeypatch.setenv("KG_PARTITION", "1")
+    with hp.SignatureTable.from_device_ptr(rec.data_ptr(), n, 0, keepalive=rec) as tab:
+        for with_run_off in (False, True):
+            qs = queries + ([run_off_query] if with_run_off else [])
+            # every query k-mer twice in a protein of its own, 30 copies of the set so that the batch has some bulk
+            prots = [(K.decode(v) + "A" + K.decode(v) + "AA").encode() for v, _ in qs] * 30
+            off = np.zeros(len(prots) + 1, dtype=np.int64)
+            np.cumsum([len(p) for p in prots], out=off[1:])
+            sb = b"".join(prots)
+            ora0 = oracle.run(img, sb, off, aa=True, lookup_mode=0, min_hits=2)
+            ora1 = oracle.run(img, sb, off, aa=True, lookup_mode=1, min_hits=2)
+            assert ora0["hits"].tobytes() == ora1["hits"].tobytes()
+            want = {}
+            for k, (v, oi) in enumerate(qs):
+                got = sorted({int(x["oI"]) for x in ora0["hits"][ora0["hits"]["container"] == k]})
+                assert got == ([oi] if oi is not None else []), (k, v, got, oi)
+            assert bool(ora0["lookup_aborted"]) == with_run_off
+            for levels, counters in (("1", False), ("2", True), ("2", False)):
+                monkeypatch.setenv("KG_PART_LEVELS", levels)
+                with tab.scan(sb, off, hp.Params(aa=True, min_hits=2, counters=counters)) as r:
+                    assert r.stats["partitioned"] == 1
+                    assert r.stats["part_levels"] == (1 if levels == "1" else 2 if counters else 3)
+                    assert r.hits().tobytes() == ora0["hits"].tobytes(), (levels, counters, with_run_off)
+                    assert r.calls().tobytes() == ora0["calls"].tobytes() and r.otu().tobytes() == ora0["otu"].tobytes()
+                    assert r.stats["lookup_ran_off"] == int(with_run_off), (levels, counters, r.stats["lookup_ran_off"])
+    del rec, host
+    torch.cuda.empty_cache()

@@ -1,0 +1,86 @@
+"""java/kmergutsjava/KmerGutsHip.java (the JNA binding a maintainer of the reference adds) against include/kmerguts_hip.h.
+No JDK in the build image, so the file cannot be compiled here; what can be checked without one is: one Java method
+per exported C function with the same number of parameters, structure fields in the C order and with matching widths,
+and the JNA level -- the reference ships jna-3.4.0.jar (build.xml:27): field order through setFieldOrder(String[]) in
+the constructor, no getFieldOrder() override (that abstract method only exists from JNA 3.5.0 on)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JAVA = open(os.path.join(ROOT, "java", "kmergutsjava", "KmerGutsHip.java")).read()
+HDR = open(os.path.join(ROOT, "include", "kmerguts_hip.h")).read()
+
+
+def _strip_comments(s):
+    s = re.sub(r"/\*.*?\*/", " ", s, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", s)
+
+
+def _c_functions():
+    h = _strip_comments(HDR)
+    out = {}
+    for m in re.finditer(r"\b(kg_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", h):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return out
+
+
+def _java_methods():
+    j = _strip_comments(JAVA)
+    out = {}
+    for m in re.finditer(r"\b(?:int|long|void|Pointer|String)\s+(kg_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", j):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if not args else len(args.split(","))
+    return out
+
+
+def _c_struct(name):
+    h = _strip_comments(HDR)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), h, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.split(None, 1)
+        for n in names.split(","):
+            fields.append((n.strip(), ctype))
+    return fields
+
+
+def _java_struct(cls):
+    j = _strip_comments(JAVA)
+    body = re.search(r"class %s extends Structure \{(.*?)\n    \}" % cls, j, flags=re.S).group(1)
+    fields = []
+    for m in re.finditer(r"public\s+(int|long|float)\s+([^;()]+);", body):
+        for n in m.group(2).split(","):
+            fields.append((n.strip(), m.group(1)))
+    order = re.search(r"setFieldOrder\(new String\[\]\s*\{(.*?)\}\)", body, flags=re.S).group(1)
+    return fields, re.findall(r'"([a-z_0-9]+)"', order)
+
+
+def test_one_java_method_per_exported_function_with_the_same_arity():
+    c, j = _c_functions(), _java_methods()
+    from kmergutsjava_amd import _native
+    assert set(c) == set(_native.EXPORTS), "header prototypes vs the ctypes export list"
+    assert set(j) == set(c), (sorted(set(c) - set(j)), sorted(set(j) - set(c)))
+    for name in c:
+        assert j[name] == c[name], (name, j[name], c[name])
+
+
+def test_structures_match_the_c_layout():
+    width = {"int32_t": "int", "uint32_t": "int", "int64_t": "long", "float": "float"}
+    for cname, jname in (("kg_params", "KgParams"), ("kg_stats", "KgStats")):
+        cf = _c_struct(cname)
+        jf, order = _java_struct(jname)
+        assert [n for n, _ in jf] == [n for n, _ in cf], (cname, jf, cf)
+        assert [t for _, t in jf] == [width[t] for _, t in cf], cname
+        assert order == [n for n, _ in cf], cname + ": setFieldOrder"
+
+
+def test_targets_the_jna_level_the_reference_ships():
+    assert "getFieldOrder" not in _strip_comments(JAVA), "getFieldOrder() does not exist in jna-3.4.0 (reference build.xml:27)"
+    assert "java.util.List" not in JAVA and "Arrays.asList" not in JAVA
+    assert 'Native.loadLibrary("kmerguts_hip", KmerGutsHip.class)' in JAVA
+    for const, val in re.findall(r"#define (KG_ERR_[A-Z]+)\s+\((-\d+)\)", HDR):
+        assert re.search(r"\b%s = %s\b" % (const, val), JAVA), const
