@@ -63,6 +63,9 @@ def main():
                     help="N > 1, secondary mode: only the CALL / OTU records (the report's content) travel inside the timed "
                          "steps; the hit records, which only the -d stream prints, stay sharded in HBM and their gather is "
                          "exercised and timed in two extra steps after the timed region ('hits_gather_probe')")
+    ap.add_argument("--no-overlap-exchange", dest="overlap_exchange", action="store_false", default=True,
+                    help="N > 1: finish every step's exchange before the next scan starts (default: the record buffers of step i "
+                         "travel while step i + 1 is scanned)")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     ap.add_argument("--strategy", choices=["auto", "direct", "partitioned"], default="auto",
                     help="scan strategy of the library (KG_PARTITION): auto picks partitioned probing for large inputs")
@@ -142,19 +145,36 @@ def main():
     gather_dev = comm_dev
     on_gpu = comm_dev.type == "cuda"
 
+    # N > 1: the exchange of step i (per-rank record buffers -> rank 0, straight out of the library's HBM buffers) is
+    # posted when scan i ends and collected when scan i + 1 has ended: the buffers travel over xGMI while the next
+    # shard is scanned (--no-overlap-exchange collects at once).  Every exchange is finished, and rank 0 has the
+    # records of every step in global order, before the timed region ends.
+    in_flight = []                                         # [(ScanResult, RecordExchange, with_hits)]
+    last = {"hits_gathered": None}
+
+    def collect():
+        while in_flight:
+            r, ex, with_hits = in_flight.pop(0)
+            got = ex.finish()              # rank 0: the records in global order (the hit records stay in HBM; their
+            if with_hits and rank == 0:    # reordering is enqueued, not waited for: it runs beside the next scan)
+                last["hits_gathered"] = int(got["hits"].shape[0])
+            r.close()
+
     def step(with_hits=False):
-        with tab.scan(None, off, params, device_ptr=seq.data_ptr()) as r:
-            st = r.stats
-            if world > 1:
-                # the exchange step: per-rank record buffers -> rank 0, straight out of the library's HBM buffers
-                kinds = ("calls", "otu") + (("hits", "container_hit_start") if with_hits else ())
-                local = {k: (r.device_view(k) if on_gpu else r.device_view(k).cpu()) for k in kinds}
-                got = kd.gather_records(local, mine, n_total, 6, gather_dev)
-                if with_hits and rank == 0:
-                    assert got["hits"].shape[0] == int(got["container_hit_start"][-1])
-            else:
-                r.calls(copy=False); r.otu(copy=False)     # the records the report needs leave HBM
-            return st
+        r = tab.scan(None, off, params, device_ptr=seq.data_ptr())
+        st = r.stats
+        if world > 1:
+            kinds = ("calls", "otu") + (("hits", "container_hit_start") if with_hits else ())
+            local = {k: (r.device_view(k) if on_gpu else r.device_view(k).cpu()) for k in kinds}
+            ex = kd.exchange_start(local, mine, n_total, 6, gather_dev, keep=r)
+            collect()                                      # the previous step's exchange: done by now
+            in_flight.append((r, ex, with_hits))
+            if not args.overlap_exchange:
+                collect()
+        else:
+            r.calls(copy=False); r.otu(copy=False)         # the records the report needs leave HBM
+            r.close()
+        return st
 
     # one instrumented launch: algorithmic bytes per residue, not timed
     with tab.scan(None, off, hotpath.Params(counters=True), device_ptr=seq.data_ptr()) as r:
@@ -165,7 +185,8 @@ def main():
     b_alg = 0.5 + 24.0 * p_bar + 24.0 * h_bar
 
     for _ in range(args.warmup):
-        step()
+        step(args.gather_hits and world > 1)
+    collect()
 
     def barrier():
         if world > 1:
@@ -186,6 +207,7 @@ def main():
         agg_ms.append(st["ms_aggregate"]); order_ms.append(st["ms_order"])
         hits, calls = st["n_hits"], st["n_calls"]
         assert st["scan_launches"] == 1, "staging buffer resized inside the timed region"
+    collect()                                              # the last step's exchange ends inside the timed region
     barrier()
     elapsed = time.perf_counter() - t1
 
@@ -193,10 +215,12 @@ def main():
     if world > 1 and not args.gather_hits:
         # outside the timed region: the same step with the per-rank hit buffers gathered to rank 0 as well
         step(True)
+        collect()
         barrier()
         t2 = time.perf_counter()
         for _ in range(2):
             step(True)
+        collect()
         barrier()
         hits_probe = {"ms_per_step": (time.perf_counter() - t2) / 2 * 1e3}
 
@@ -243,9 +267,12 @@ def main():
                        "total_bp_all_ranks": int(all_off[-1]) * (1 if strong else world),
                        "num_sigs": args.num_sigs, "residues_rank0": int(residues), "residues_all_ranks": int(residues_all),
                        "hits_rank0": int(hits), "hits_all_ranks": int(hits_all), "calls_rank0": int(calls),
-                       "exchange": (None if world == 1 else "per-rank %s buffers -> rank 0, %s point-to-point, device buffers"
+                       "exchange": (None if world == 1 else "per-rank %s buffers -> rank 0, %s point-to-point, device buffers, %s"
                                     % ("CALL/OTU/hit" if args.gather_hits else "CALL/OTU",
-                                       "RCCL" if args.backend == "nccl" else args.backend)),
+                                       "RCCL" if args.backend == "nccl" else args.backend,
+                                       "step i's transfers overlap scan i + 1 (all finished inside the timed region)"
+                                       if args.overlap_exchange else "finished before the next scan")),
+                       "hits_gathered_rank0": last["hits_gathered"],
                        "hits_gather_probe": (None if hits_probe is None else dict(
                            hits_probe, note="two extra steps after the timed region, hit records (24 B each) gathered to rank 0 "
                                             "too and put in global (container, from0InProt) order on the device",

@@ -64,12 +64,29 @@ def _as_u8(x, device) -> torch.Tensor:
     return t.to(device)
 
 
-def gather_buffers(bufs: List[torch.Tensor], dst: int = 0) -> Optional[List[List[torch.Tensor]]]:
-    """Gather K 1-D uint8 buffers of rank-dependent length to rank dst (all ranks call, same K).
-    Returns on dst: out[k][r] = buffer k of rank r (its own buffers are passed through, not copied); None elsewhere.
-    Sizes travel in one gather towards dst -- only dst needs them, and only dst pays the host round trip that reads
-    them; the senders post their transfers at once -- the payload in one batch of point-to-point transfers, so only dst
-    allocates."""
+class _Pending:
+    """The transfers of one gather_buffers_start call: requests, receive buffers (rank dst) and whatever must stay alive
+    until they are done (the senders' buffers belong to the library's result object)."""
+
+    def __init__(self, reqs, out, dev, keep):
+        self.reqs, self.out, self.dev, self.keep = reqs, out, dev, keep
+
+    def wait(self):
+        """On return the payload has arrived (dst) / has left (senders).  With RCCL a request's wait() makes torch's current
+        stream wait for the transfer; the stream is then synchronised so that the senders' buffers may be freed."""
+        for req in self.reqs:
+            req.wait()
+        self.reqs = []
+        if self.dev.type == "cuda":
+            torch.cuda.current_stream(self.dev).synchronize()
+        self.keep = None
+        return self.out
+
+
+def gather_buffers_start(bufs: List[torch.Tensor], dst: int = 0, keep=None) -> _Pending:
+    """First half of gather_buffers: the sizes travel in one gather towards dst -- only dst needs them, and only dst pays
+    the host round trip that reads them -- and the payload transfers are POSTED (one batch of point-to-point transfers, so
+    only dst allocates); the caller goes on (e.g. into the next scan) and collects with .wait()."""
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = bufs[0].device
     mine = torch.tensor([b.numel() for b in bufs], dtype=torch.int64, device=dev)
@@ -92,12 +109,14 @@ def gather_buffers(bufs: List[torch.Tensor], dst: int = 0) -> Optional[List[List
         for b in bufs:
             if b.numel():
                 ops.append(dist.P2POp(dist.isend, b, dst))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    if dev.type == "cuda":
-        torch.cuda.current_stream(dev).synchronize()     # the senders' buffers belong to the library: done before they are freed
-    return out
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return _Pending(reqs, out, dev, (bufs, keep))
+
+
+def gather_buffers(bufs: List[torch.Tensor], dst: int = 0) -> Optional[List[List[torch.Tensor]]]:
+    """Gather K 1-D uint8 buffers of rank-dependent length to rank dst (all ranks call, same K).
+    Returns on dst: out[k][r] = buffer k of rank r (its own buffers are passed through, not copied); None elsewhere."""
+    return gather_buffers_start(bufs, dst).wait()
 
 
 def _restore_small(recs_by_rank, idx_by_rank, n_total_seqs: int, per: int, dtype):
@@ -127,44 +146,74 @@ def restore_hits(hits_by_rank: List[torch.Tensor], chs_by_rank: List[torch.Tenso
                  n_total_seqs: int, per: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Per-rank hit buffers (uint8, 24 B records ordered by local container and position) + their
     container_hit_start (int64) + the ranks' sequence indices -> (hits int32[n, 6], container_hit_start int64) in
-    global numbering, on the device the buffers are on.  Every record goes straight to its final index:
-        dst = start[global container] + (its index in the rank's list - the rank's start of its local container)."""
+    global numbering, on the device the buffers are on.  The records of one sequence are one contiguous piece of its
+    rank's buffer (its containers are adjacent) and one contiguous piece of the result, so the work is a segmented copy:
+    per rank one shift per local sequence, spread over its records, and one index_copy_ (nothing waits for the host)."""
     dev = hits_by_rank[0].device
     n_cont = n_total_seqs * per
     counts = torch.zeros(n_cont, dtype=torch.int64, device=dev)
     ar = torch.arange(per, dtype=torch.int64, device=dev)
-    gmaps = []
     for chs, idx in zip(chs_by_rank, idx_by_rank):
-        g = (idx[:, None] * per + ar[None, :]).reshape(-1)              # global id of every local container
-        gmaps.append(g)
-        if g.numel():
+        if idx.numel():
+            g = (idx[:, None] * per + ar[None, :]).reshape(-1)          # global id of every local container
             counts[g] = chs[1:] - chs[:-1]
     starts = torch.zeros(n_cont + 1, dtype=torch.int64, device=dev)
     torch.cumsum(counts, 0, out=starts[1:])
-    out = torch.empty((int(starts[-1]), 6), dtype=torch.int32, device=dev)
-    for hb, chs, g in zip(hits_by_rank, chs_by_rank, gmaps):
+    total = sum(int(hb.numel()) // 24 for hb in hits_by_rank)           # (sizes are known on the host: no read-back)
+    out = torch.empty((total, 6), dtype=torch.int32, device=dev)
+    for hb, chs, idx in zip(hits_by_rank, chs_by_rank, idx_by_rank):
         h = hb.view(torch.int32).view(-1, 6)
-        if h.shape[0] == 0:
+        n = h.shape[0]
+        if n == 0:
             continue
-        lc = h[:, 0].to(torch.int64) & 0xFFFFFFFF
-        gc = g[lc]
-        dst = starts[gc] + (torch.arange(h.shape[0], dtype=torch.int64, device=dev) - chs[lc])
-        out[dst] = h
-        out[dst, 0] = gc.to(torch.int32)                                  # container ids < 2^31 (kg_scan's own limit)
+        seq_lo = chs[:-1:per]                                            # first record of every local sequence
+        seq_n = chs[per::per] - seq_lo
+        k = torch.arange(idx.numel(), dtype=torch.int64, device=dev)
+        to = torch.repeat_interleave(starts[idx * per] - seq_lo, seq_n, output_size=n)       # where a record moves to
+        cshift = torch.repeat_interleave(((idx - k) * per).to(torch.int32), seq_n, output_size=n)
+        hh = h.clone()
+        hh[:, 0] += cshift                                               # container ids < 2^31 (kg_scan's own limit)
+        out.index_copy_(0, torch.arange(n, dtype=torch.int64, device=dev) + to, hh)
     return out, starts
 
 
-def gather_records(local: Dict[str, object], shard_idx: np.ndarray, n_total_seqs: int, per: int, device=None) -> Optional[dict]:
-    """Gather per-rank results to rank 0 and restore the original sequence order.
+class RecordExchange:
+    """One exchange step in two halves (exchange_start / .finish), so that a caller can run the next scan while the
+    record buffers of this one travel: start posts the transfers (rank 0 learns the sizes and posts the receives), finish
+    waits for them and, on rank 0, puts the records back in the original sequence order."""
 
-    local: {"calls": CALL records, "otu": OTU records (one per local sequence)} and optionally
-    {"hits": hit records, "container_hit_start": int64[n_local_containers + 1]}; numpy arrays or torch tensors
-    (ScanResult.device_view: the library's own HBM buffers), container ids local to the shard
-    (container // per = local sequence index).  "container_hit_start" may be omitted for numpy hit records.
-    Returns on rank 0 {"calls", "container_call_start", "otu"} as numpy arrays [+ "hits" (int32[n, 6] tensor on the
-    exchange device; .cpu().numpy().view(HIT_DTYPE) gives records) and "container_hit_start" (int64 tensor)] in
-    global numbering, None elsewhere."""
-    from . import _native as N
+    def __init__(self, pending, with_hits, n_total_seqs, per):
+        self.pending, self.with_hits, self.n_total_seqs, self.per = pending, with_hits, n_total_seqs, per
+
+    def finish(self) -> Optional[dict]:
+        from . import _native as N
+        got = self.pending.wait()
+        self.pending = None
+        if got is None:
+            return None
+        n_total_seqs, per = self.n_total_seqs, self.per
+        world = dist.get_world_size()
+        idx_t = [b.view(torch.int64) for b in got[0]]
+        idx = [t.cpu().numpy() for t in idx_t]
+        calls = [np.frombuffer(b.cpu().numpy().tobytes(), dtype=N.CALL_DTYPE) for b in got[1]]
+        otus = [np.frombuffer(b.cpu().numpy().tobytes(), dtype=N.OTU_DTYPE) for b in got[2]]
+        otu = np.zeros(n_total_seqs, dtype=N.OTU_DTYPE)
+        seen = np.zeros(n_total_seqs, dtype=np.int64)
+        for r in range(world):
+            otu[idx[r]] = otus[r]
+            seen[idx[r]] += 1
+        assert (seen == 1).all(), "every sequence must belong to exactly one rank"
+        out = {"otu": otu}
+        out["calls"], out["container_call_start"] = _restore_small(calls, idx, n_total_seqs, per, N.CALL_DTYPE)
+        if self.with_hits:
+            out["hits"], out["container_hit_start"] = restore_hits(got[3], [b.view(torch.int64) for b in got[4]], idx_t,
+                                                                   n_total_seqs, per)
+        return out
+
+
+def exchange_start(local: Dict[str, object], shard_idx: np.ndarray, n_total_seqs: int, per: int, device=None, keep=None) -> RecordExchange:
+    """First half of gather_records (same arguments).  `keep`: an object that owns the buffers in `local` (the
+    ScanResult) and must not be freed before .finish() has returned."""
     device = torch.device(device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
@@ -177,23 +226,17 @@ def gather_records(local: Dict[str, object], shard_idx: np.ndarray, n_total_seqs
             cont = np.asarray(local["hits"]["container"], dtype=np.int64)
             chs = np.searchsorted(cont, np.arange(len(idx_np) * per + 1))
         bufs += [_as_u8(local["hits"], device), _as_u8(chs if isinstance(chs, torch.Tensor) else np.asarray(chs, dtype=np.int64), device)]
-    got = gather_buffers(bufs, 0)
-    if got is None:
-        return None
-    world = dist.get_world_size()
-    idx_t = [b.view(torch.int64) for b in got[0]]
-    idx = [t.cpu().numpy() for t in idx_t]
-    calls = [np.frombuffer(b.cpu().numpy().tobytes(), dtype=N.CALL_DTYPE) for b in got[1]]
-    otus = [np.frombuffer(b.cpu().numpy().tobytes(), dtype=N.OTU_DTYPE) for b in got[2]]
-    otu = np.zeros(n_total_seqs, dtype=N.OTU_DTYPE)
-    seen = np.zeros(n_total_seqs, dtype=np.int64)
-    for r in range(world):
-        otu[idx[r]] = otus[r]
-        seen[idx[r]] += 1
-    assert (seen == 1).all(), "every sequence must belong to exactly one rank"
-    out = {"otu": otu}
-    out["calls"], out["container_call_start"] = _restore_small(calls, idx, n_total_seqs, per, N.CALL_DTYPE)
-    if with_hits:
-        out["hits"], out["container_hit_start"] = restore_hits(got[3], [b.view(torch.int64) for b in got[4]], idx_t,
-                                                               n_total_seqs, per)
-    return out
+    return RecordExchange(gather_buffers_start(bufs, 0, keep=(local, keep)), with_hits, n_total_seqs, per)
+
+
+def gather_records(local: Dict[str, object], shard_idx: np.ndarray, n_total_seqs: int, per: int, device=None) -> Optional[dict]:
+    """Gather per-rank results to rank 0 and restore the original sequence order.
+
+    local: {"calls": CALL records, "otu": OTU records (one per local sequence)} and optionally
+    {"hits": hit records, "container_hit_start": int64[n_local_containers + 1]}; numpy arrays or torch tensors
+    (ScanResult.device_view: the library's own HBM buffers), container ids local to the shard
+    (container // per = local sequence index).  "container_hit_start" may be omitted for numpy hit records.
+    Returns on rank 0 {"calls", "container_call_start", "otu"} as numpy arrays [+ "hits" (int32[n, 6] tensor on the
+    exchange device; .cpu().numpy().view(HIT_DTYPE) gives records) and "container_hit_start" (int64 tensor)] in
+    global numbering, None elsewhere."""
+    return exchange_start(local, shard_idx, n_total_seqs, per, device).finish()

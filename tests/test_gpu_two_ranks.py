@@ -36,12 +36,12 @@ def test_two_ranks_share_the_gpu_hip_path_vs_unsharded(tmp_path):
     assert r.returncode == 0 and (tmp_path / "ok").exists(), r.stdout.decode()[-2000:] + r.stderr.decode()[-4000:]
 
 
-@pytest.mark.parametrize("gather", [True, False])
-def test_bench_self_launch_two_ranks(gather):
+@pytest.mark.parametrize("gather,overlap", [(True, True), (True, False), (False, True)])
+def test_bench_self_launch_two_ranks(gather, overlap):
     env = _clean_env()
     env["KG_BENCH_DEVICE"] = "0"                       # both ranks on the one GPU
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--total-bp", "40000000",
-           "--num-sigs", "20000003", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + ([] if gather else ["--no-gather-hits"])
+           "--num-sigs", "20000003", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + ([] if gather else ["--no-gather-hits"]) + ([] if overlap else ["--no-overlap-exchange"])
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-2000:] + r.stderr.decode()[-4000:]
     line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
@@ -49,5 +49,6 @@ def test_bench_self_launch_two_ranks(gather):
     cfg = line["config"]
     assert cfg["total_bp_all_ranks"] == 40000000 and cfg["hits_all_ranks"] > 0
     assert ("CALL/OTU/hit" in cfg["exchange"]) == gather
+    assert cfg["hits_gathered_rank0"] == (cfg["hits_all_ranks"] if gather else None)      # every rank's hits reached rank 0
     assert (cfg["hits_gather_probe"] is None) == gather
     assert 0 < line["roofline"]["frac_step"] <= line["roofline"]["frac"] * 1.05
