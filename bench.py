@@ -150,7 +150,7 @@ def main():
     # shard is scanned (--no-overlap-exchange collects at once).  Every exchange is finished, and rank 0 has the
     # records of every step in global order, before the timed region ends.
     in_flight = []                                         # [(ScanResult, RecordExchange, with_hits)]
-    last = {"hits_gathered": None}
+    last = {"hits_gathered": None}                         # hit records rank 0 received in the latest collected step
 
     def collect():
         while in_flight:
@@ -210,6 +210,7 @@ def main():
     collect()                                              # the last step's exchange ends inside the timed region
     barrier()
     elapsed = time.perf_counter() - t1
+    hits_gathered_timed = last["hits_gathered"]
 
     hits_probe = None
     if world > 1 and not args.gather_hits:
@@ -272,7 +273,7 @@ def main():
                                        "RCCL" if args.backend == "nccl" else args.backend,
                                        "step i's transfers overlap scan i + 1 (all finished inside the timed region)"
                                        if args.overlap_exchange else "finished before the next scan")),
-                       "hits_gathered_rank0": last["hits_gathered"],
+                       "hits_gathered_rank0": hits_gathered_timed,
                        "hits_gather_probe": (None if hits_probe is None else dict(
                            hits_probe, note="two extra steps after the timed region, hit records (24 B each) gathered to rank 0 "
                                             "too and put in global (container, from0InProt) order on the device",

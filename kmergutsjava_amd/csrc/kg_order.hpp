@@ -1,0 +1,318 @@
+// kg_order.hpp -- ordered placement of the partitioned scan's hits without a random access.
+//
+// The partitioned scan finds its hits in table-slot order, i.e. in random order with respect to the windows they
+// belong to; hits[] has to be ordered by (container, from0InProt) (the reference sorts each container's hits,
+// KGJ:460-465).  Until round 2 every hit set a bit in a 64-bit mask of its (block, row) with a global atomicOr, read a
+// 24-byte row record and was stored at off[row] + popcount(mask bits before it): three random 128-byte lines per
+// 24-byte record (21.7 GB of traffic to deliver 0.88 GB of hit records per Gbp), 5.2 ms of a 20.7 ms stage.
+//
+// Now every query entry carries, instead of (block, row, lane), its KEY = the window's rank in the final order:
+//     key = row_index * 64 + olane,   row_index = index of the window's 64-window row in the container-major row order
+//                                     (kg_device.hpp, row_index: rows of one container are consecutive and ascend with
+//                                     the position), olane = the window's rank inside its row by position
+//                                     ('+' rows and proteins: the lane; '-' rows: 63 - lane)
+// so that ascending key IS (container, from0InProt) order, and the unordered hit list {key, payload} is ordered by a
+// two-level partition by key range followed by an in-LDS ranking, all of it streaming:
+//   hit_hist_kernel        hits per GROUP (2^gshift rows = 2^(gshift+6) keys; <= kMaxGroups groups per chunk of the batch),
+//                          accumulated in LDS by persistent workgroups, one global atomic per (workgroup, non-empty group)
+//   group_scan_kernel      exclusive scan of the group counts: where every group starts -- exact, nothing is over-allocated
+//   hit_partition_kernel   <first> by the high part of the group number (groups / 128), <second> by the low part: tile of
+//                          2048 records, one returning LDS atomic per record = its rank in its digit, one global atomic
+//                          per (tile, digit), records leave in runs of consecutive 24-byte records
+//   group_place_kernel     one workgroup per group: the rows' 64-bit hit masks in LDS (ds_or), their prefix sum, then
+//                          every record goes to start(group) + prefix(row) + popcount(mask bits below it) with its
+//                          (container, from0InProt) filled in from the row's geometry record; also writes off[row],
+//                          from which container_hit_start[] is read
+// A chunk of the batch is a contiguous range of rows and its hits a contiguous range of hits[] that starts at *base
+// (chained on the device by chunk_base_kernel), as before.
+#pragma once
+
+#include "kg_device.hpp"
+#include "kg_partition.hpp"
+
+namespace kg {
+
+constexpr uint32_t kHThreads = 512;
+constexpr uint32_t kHPer = 4;                       // records per thread and tile
+constexpr uint32_t kHTile = kHThreads * kHPer;      // 2048 records = 48 KB of LDS
+constexpr uint32_t kHDigits = 128;                  // groups per first-level bucket
+constexpr uint32_t kMaxGroups = kHDigits * kHDigits;
+
+// per-row geometry: what turns (row, olane) back into (container, from0InProt)
+struct RowGeo { uint32_t container; int32_t pos_first; };      // from0InProt of olane 0
+
+// One record per row of the batch, written once per scan in block-major order (six coalesced streams).
+template <bool AA>
+__global__ void row_geo_kernel(const BlockDesc *__restrict__ blocks, uint32_t n_blocks, RowGeo *__restrict__ geo)
+{
+    constexpr uint32_t ROWS = AA ? 1 : 6;
+    const uint64_t tl = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tl >= (uint64_t)n_blocks * ROWS) return;
+    // thread -> (row kind r, block it): consecutive threads, consecutive blocks of one kind: consecutive rows of a container
+    const uint32_t r = (uint32_t)(tl / n_blocks), it = (uint32_t)(tl % n_blocks);
+    const BlockDesc bd = blocks[it];
+    RowGeo g;
+    int32_t pos0;
+    row_record_key<AA>(bd, (int)r, 0, &g.container, &pos0);
+    g.pos_first = (!AA && r >= 3) ? pos0 - 63 : pos0;            // '-' rows: positions descend with the lane (olane = 63 - lane)
+    geo[row_index<AA>(bd, it, (int)r)] = g;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kHThreads) void hit_hist_kernel(const kg_hit *__restrict__ ulist, const uint32_t *__restrict__ chunk_used,
+                                                             const unsigned long long *__restrict__ cursor, uint64_t ulist_cap,
+                                                             uint32_t g0, uint32_t gs /* 6 + gshift */, uint32_t n_groups,
+                                                             uint32_t *ghist /* [n_groups], zeroed */)
+{
+    extern __shared__ uint32_t h_lds[];
+    for (uint32_t g = threadIdx.x; g < n_groups; g += kHThreads) h_lds[g] = 0;
+    __syncthreads();
+    const unsigned long long cur = *cursor;
+    const uint32_t n_chunks = (uint32_t)((cur < ulist_cap ? cur : ulist_cap) / kUChunk);
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const uint32_t used = chunk_used[c];
+        for (uint32_t k = threadIdx.x; k < used; k += kHThreads) {
+            const uint32_t g = (ulist[(uint64_t)c * kUChunk + k].container >> gs) - g0;
+            if (g < n_groups) atomicAdd(&h_lds[g], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < n_groups; g += kHThreads)
+        if (h_lds[g]) atomicAdd(&ghist[g], h_lds[g]);
+}
+
+// single workgroup of 1024: gbase[0 .. n_groups] = exclusive scan of ghist (gbase[n_groups] = the chunk's hits);
+// cur1[d] = start of first-level bucket d, cur2[g] = gbase[g]: the cursors the two partition passes draw from
+__global__ __launch_bounds__(1024) void group_scan_kernel(const uint32_t *__restrict__ ghist, uint32_t n_groups, uint32_t *__restrict__ gbase,
+                                                          uint32_t *__restrict__ cur1, uint32_t *__restrict__ cur2, uint64_t *total_out)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t b = 0; b < n_groups; b += 1024) {
+        const uint32_t i = b + threadIdx.x;
+        const uint32_t x = i < n_groups ? ghist[i] : 0u;
+        uint32_t incl = x;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, all = 0;
+        for (int w = 0; w < 16; w++) {
+            const uint32_t s = wsum[w];
+            if (w < wave) wbase += s;
+            all += s;
+        }
+        const uint32_t c = carry;
+        if (i < n_groups) {
+            const uint32_t e = c + wbase + incl - x;
+            gbase[i] = e;
+            cur2[i] = e;
+            if ((i & (kHDigits - 1)) == 0) cur1[i / kHDigits] = e;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        gbase[n_groups] = carry;
+        cur1[(n_groups + kHDigits - 1) / kHDigits] = carry;      // end sentinel of the last first-level bucket
+        *total_out = carry;
+    }
+}
+
+// One partition pass.  FIRST: input = the unordered list in its reservation chunks (kUChunk slots, chunk_used filled),
+// digit = group / kHDigits, cursors cur1[]; else: input = the first pass's output, bucket d1 = [seg[d1], seg[d1 + 1]) with
+// seg[] = the group starts at multiples of kHDigits (gbase), digit = group % kHDigits, cursors cur2[d1 * kHDigits + digit].
+template <bool FIRST>
+__global__ __launch_bounds__(kHThreads) void hit_partition_kernel(const kg_hit *__restrict__ in, const uint32_t *__restrict__ chunk_used,
+                                                                  const unsigned long long *__restrict__ cursor, uint64_t in_cap,
+                                                                  const uint32_t *__restrict__ gbase, uint32_t n_groups, uint32_t g0, uint32_t gs,
+                                                                  uint32_t *cur, kg_hit *__restrict__ out, uint64_t out_cap)
+{
+    __shared__ __attribute__((aligned(16))) kg_hit stage[kHTile];
+    __shared__ uint32_t hist[kHDigits], cnt[kHDigits], sbase[kHDigits], gb[kHDigits];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid < kHDigits) hist[tid] = 0;
+    const uint32_t n_d1 = (n_groups + kHDigits - 1) / kHDigits;
+    uint32_t n_res = 0;
+    if (FIRST) {
+        const unsigned long long cc = *cursor;
+        n_res = (uint32_t)((cc < in_cap ? cc : in_cap) / kUChunk);
+    }
+    // work items: FIRST: tiles of kHTile / kUChunk reservation chunks; else the tiles of all first-level buckets, numbered
+    // through (tstart[d1] = tiles of the buckets before d1), so that every workgroup has work whatever the bucket sizes
+    __shared__ uint32_t tstart[kHDigits + 1];
+    if (!FIRST) {
+        if (tid == 0) {
+            uint32_t acc = 0;
+            for (uint32_t d = 0; d < n_d1; d++) {
+                tstart[d] = acc;
+                acc += (gbase[min((d + 1) * kHDigits, n_groups)] - gbase[d * kHDigits] + kHTile - 1) / kHTile;
+            }
+            for (uint32_t d = n_d1; d <= kHDigits; d++) tstart[d] = acc;
+        }
+        __syncthreads();
+    }
+    const uint32_t n_items = FIRST ? (n_res + kHTile / kUChunk - 1) / (kHTile / kUChunk) : tstart[kHDigits];
+    {
+        for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+            uint32_t d1 = 0, tile = item;
+            if (!FIRST) {
+                uint32_t lo_d = 0, hi_d = n_d1;                      // largest d with tstart[d] <= item (buckets without tiles are skipped)
+                while (hi_d - lo_d > 1) {
+                    const uint32_t mid = (lo_d + hi_d) / 2;
+                    if (tstart[mid] <= item) lo_d = mid; else hi_d = mid;
+                }
+                d1 = lo_d;
+                tile = item - tstart[d1];
+            }
+            const uint32_t seg_lo = FIRST ? 0u : gbase[d1 * kHDigits];
+            const uint32_t seg_hi = FIRST ? 0u : gbase[min((d1 + 1) * kHDigits, n_groups)];
+            kg_hit rec[kHPer];
+            uint32_t dr[kHPer];
+#pragma unroll
+            for (uint32_t k = 0; k < kHPer; k++) {
+                const uint32_t i = k * kHThreads + tid;            // slot inside the tile
+                bool ok;
+                uint64_t at;
+                if (FIRST) {
+                    const uint32_t c = tile * (kHTile / kUChunk) + i / kUChunk;
+                    ok = c < n_res && (i % kUChunk) < chunk_used[c];
+                    at = (uint64_t)c * kUChunk + (i % kUChunk);
+                } else {
+                    at = (uint64_t)seg_lo + (uint64_t)tile * kHTile + i;
+                    ok = at < seg_hi;
+                }
+                dr[k] = ~0u;
+                if (ok) {
+                    rec[k] = in[at];
+                    const uint32_t g = (rec[k].container >> gs) - g0;
+                    if (g < n_groups) {                              // (always; a record outside would be a kernel bug: dropped)
+                        const uint32_t d = FIRST ? g / kHDigits : g % kHDigits;
+                        dr[k] = (d << 16) | atomicAdd(&hist[d], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < kHDigits) {                                    // two waves: scan of 128 counts, one global atomic per digit
+                const uint32_t c = hist[tid];
+                uint32_t incl = c;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t y = __shfl_up(incl, off);
+                    if ((int)lane >= off) incl += y;
+                }
+                cnt[tid] = c;
+                sbase[tid] = incl - c;                               // (second wave: + the first wave's total, below)
+                gb[tid] = c ? atomicAdd(&cur[FIRST ? tid : d1 * kHDigits + tid], c) : 0u;
+                hist[tid] = 0;
+            }
+            __syncthreads();
+            const uint32_t first_half = sbase[63] + cnt[63];
+#pragma unroll
+            for (uint32_t k = 0; k < kHPer; k++)
+                if (dr[k] != ~0u) {
+                    const uint32_t d = dr[k] >> 16;
+                    stage[sbase[d] + (d >= 64 ? first_half : 0u) + (dr[k] & 0xFFFFu)] = rec[k];
+                }
+            __syncthreads();
+            for (uint32_t d = wave; d < kHDigits; d += kHThreads / 64u) {
+                const uint32_t n = cnt[d];
+                if (n == 0) continue;
+                const uint32_t s0 = sbase[d] + (d >= 64 ? first_half : 0u);
+                const uint64_t o0 = gb[d];
+                for (uint32_t i = lane; i < n; i += 64u)
+                    if (o0 + i < out_cap) out[o0 + i] = stage[s0 + i];
+            }
+            __syncthreads();                                         // stage / cnt / sbase / gb are rewritten by the next tile
+        }
+    }
+}
+
+// One workgroup per group of 2^gshift rows.  Dynamic LDS: (8 + 4) << gshift bytes.
+template <bool AA>
+__global__ __launch_bounds__(kHThreads) void group_place_kernel(const kg_hit *__restrict__ in, const uint32_t *__restrict__ gbase, uint32_t n_groups,
+                                                                uint32_t g0, uint32_t gshift, uint32_t row_lo, uint32_t row_hi /* the chunk's rows */,
+                                                                const RowGeo *__restrict__ geo, const uint64_t *__restrict__ base,
+                                                                kg_hit *__restrict__ hits, uint64_t hits_cap, uint32_t *__restrict__ offs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char p_lds[];
+    const uint32_t R = 1u << gshift;
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(p_lds);
+    uint32_t *pre = reinterpret_cast<uint32_t *>(masks + R);
+    __shared__ uint32_t wsum[kHThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t chunk_base = *base;
+    const uint32_t per = R / kHThreads > 0 ? R / kHThreads : 1u;        // rows per thread in the scan (R >= kHThreads, or some threads idle)
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint32_t lo = gbase[g], n = gbase[g + 1] - lo;
+        const uint64_t row0 = (uint64_t)(g0 + g) << gshift;
+        for (uint32_t i = tid; i < R; i += kHThreads) masks[i] = 0ull;
+        __syncthreads();
+        // the group's records are read once and wait in registers for their rank when there are at most kKeep per thread
+        // (a group of 1024 rows holds ~1150 hits of the 1 Gbp contig mix); larger groups are read a second time
+        constexpr uint32_t kKeep = 4;
+        const bool keep = n <= kHThreads * kKeep;
+        kg_hit rk[kKeep];
+        if (keep) {
+#pragma unroll
+            for (uint32_t j = 0; j < kKeep; j++) {
+                const uint32_t k = j * kHThreads + tid;
+                if (k < n) {
+                    rk[j] = in[lo + k];
+                    atomicOr(&masks[(rk[j].container >> 6) & (R - 1u)], 1ull << (rk[j].container & 63u));
+                }
+            }
+        } else {
+            for (uint32_t k = tid; k < n; k += kHThreads) {
+                const uint32_t key = in[lo + k].container;
+                atomicOr(&masks[(key >> 6) & (R - 1u)], 1ull << (key & 63u));
+            }
+        }
+        __syncthreads();
+        // exclusive prefix of the rows' hit counts: `per` consecutive rows per thread, then a workgroup scan
+        uint32_t mine = 0;
+        const uint32_t r_lo = tid * per;
+        if (r_lo < R)
+            for (uint32_t i = 0; i < per; i++) mine += (uint32_t)__popcll(masks[r_lo + i]);
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += y;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+        if (r_lo < R)
+            for (uint32_t i = 0; i < per; i++) {
+                pre[r_lo + i] = run;
+                const uint64_t row = row0 + r_lo + i;
+                if (row >= row_lo && row < row_hi) offs[row] = (uint32_t)(chunk_base + lo + run);
+                run += (uint32_t)__popcll(masks[r_lo + i]);
+            }
+        __syncthreads();
+        auto place = [&](kg_hit h) {
+            const uint32_t key = h.container, rl = (key >> 6) & (R - 1u), ol = key & 63u;
+            const RowGeo gr = geo[key >> 6];
+            const uint64_t dst = chunk_base + lo + pre[rl] + (uint32_t)__popcll(masks[rl] & ((1ull << ol) - 1ull));
+            h.container = gr.container;
+            h.from0InProt = gr.pos_first + (int32_t)ol;
+            if (dst < hits_cap) hits[dst] = h;              // only out of range when a list overflowed: that scan is re-run
+        };
+        if (keep) {
+#pragma unroll
+            for (uint32_t j = 0; j < kKeep; j++)
+                if (j * kHThreads + tid < n) place(rk[j]);
+        } else {
+            for (uint32_t k = tid; k < n; k += kHThreads) place(in[lo + k]);
+        }
+        __syncthreads();                                    // masks / pre are rewritten by the next group
+    }
+}
+
+}  // namespace kg

@@ -20,15 +20,15 @@
 //                          empty slot ends it, a fingerprint match or an undecided window becomes a 16-byte
 //                          candidate record
 //   verify_kernel        : one lane per candidate: (continue the tag walk,) fetch the 24-byte record, compare the
-//                          key; a hit sets bit `lane` in the 64-bit mask of its (block,row) and appends
-//                          {id, payload} to an unordered list
+//                          key; a hit appends {key, payload} to an unordered list
 //   overflow_probe_kernel: the groups the scatter pass could not fit into their regions
-//   rows_from_masks      : popcount of the masks -> counts[] in container-major row order (then a prefix sum)
-//   row_info / place_unordered : unordered list -> hits[] at off[row] + popcount(mask bits before the lane)
+//   kg_order.hpp         : unordered list -> hits[] in (container, from0InProt) order: two partition passes by key range
+//                          and an in-LDS ranking per group of rows, all streaming
 // The batch is processed in chunks of whole sequences; scatter, tag pass and verification + placement of successive
 // chunks run on three streams (kmerguts_hip.hip, scan_impl).
 //
-// Entry (64 bit): low word = quotient << shift | slot_low, high word = id = block << 9 | row << 6 | lane;
+// Entry (64 bit): low word = quotient << shift | slot_low, high word = id = the window's key (window_key: its rank in the
+// final order of the hit records);
 // value = quotient * numSigs + (bucket << shift | slot_low) exactly.
 #pragma once
 
@@ -44,6 +44,15 @@ constexpr int kProbeN = KG_PROBE_N;                  // queries per lane per ite
 constexpr uint32_t kUChunk = 512;           // records per reservation of the unordered hit list
 
 constexpr uint64_t kEntInvalid = ~0ull;     // filler entry (padding of a 16-entry group)
+
+// The id an entry carries = the window's KEY = its rank in the final (container, from0InProt) order (kg_order.hpp):
+// row_index * 64 + olane; r and bd are wave-uniform.
+template <bool AA>
+__device__ __forceinline__ uint32_t window_key(const BlockDesc &bd, uint32_t it, int r, int lane)
+{
+    const uint32_t ol = (!AA && r >= 3) ? 63u - (uint32_t)lane : (uint32_t)lane;
+    return (row_index<AA>(bd, it, r) << 6) | ol;
+}
 constexpr int kScatterWaves = 16;           // waves per scatter workgroup (one workgroup per CU: its LDS holds the buffers)
 constexpr uint32_t kGroup = 16;             // entries per write-combining buffer = one 128-byte line
 
@@ -56,6 +65,10 @@ inline size_t scatter_lds_bytes(uint32_t n_buckets)
 }
 
 // ---------------------------------------------------------------------------------------
+// (Storing every entry straight at its place in the region instead -- counters only in LDS, the XCD's write-back L2 as
+//  the write-combining buffer: half the VALU, a fifth of the LDS -- was built and measured in round 3: 17.3 ms per Gbp
+//  against 7.8 for this kernel; 1.36e9 scattered 8-byte stores cost more than everything they save:
+//  profiles/r03_experiments.md.)
 // Scatter pass: every window is encoded once; its entry goes into the workgroup's 16-entry buffer of its
 // bucket (LDS); a full buffer is written as one aligned 128-byte line into the workgroup's private region of
 // that bucket.  Regions are over-allocated (cap entries each, no counting pass); a group that does not fit its
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
                 valid = valid && slot < limit32;                        // beyond the stream: never probed
                 bk[r] = slot >> shift;
                 const uint32_t low = (q << shift) | (slot & ((1u << shift) - 1u));
-                const uint32_t id = ((block_lo + it) << 9) | ((uint32_t)r << 6) | (uint32_t)lane;
+                const uint32_t id = window_key<AA>(bd, block_lo + it, r, lane);
                 e[r] = ((uint64_t)id << 32) | low;
                 if (valid) pend |= 1u << r;
             }
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(64 * kLowcWaves) void lowc_blocks_kernel(
             if (valid && slot >= limit32) ran_off = true;
             bool pend = valid && slot < limit32;
             const uint32_t bkt = slot >> shift;
-            const uint64_t e = ((uint64_t)((it << 9) | ((uint32_t)r << 6) | (uint32_t)lane) << 32) | ((q << shift) | (slot & ((1u << shift) - 1u)));
+            const uint64_t e = ((uint64_t)window_key<AA>(bd, it, r, lane) << 32) | ((q << shift) | (slot & ((1u << shift) - 1u)));
             // big same-bucket sets first: one reservation and one coalesced store per set
             for (int pass = 0; pass < 4; pass++) {
                 const unsigned long long mp = __ballot(pend);
@@ -445,16 +458,14 @@ __global__ __launch_bounds__(64 * kLowcWaves) void lowc_blocks_kernel(
 // State of a wave's reservation in the unordered hit list.
 struct UListState { unsigned long long base; uint32_t used; bool have; };
 
-// Probe N entries of bucket b per lane and emit the hits: set the lane's bit in the 64-bit mask of its
-// (block,row) and append {id, payload} to the unordered list (wave-private chunk reservations).
+// Probe N entries of bucket b per lane and emit the hits: {key, payload} appended to the unordered list (wave-private
+// chunk reservations).
 template <bool AA, int N, bool COUNTERS>
 __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, uint32_t shift, const uint64_t (&e)[N],
                                               kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used,
-                                              unsigned long long *cursor, uint64_t ulist_cap,
-                                              unsigned long long *__restrict__ masks, UListState &u,
+                                              unsigned long long *cursor, uint64_t ulist_cap, UListState &u,
                                               unsigned long long &ctr_slots, bool &ran_off, int lane)
 {
-    constexpr uint32_t ROWS = AA ? 1 : 6;
     uint64_t val[N], slot[N];
     bool valid[N];
     uint32_t id[N], fp[N];
@@ -478,7 +489,6 @@ __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, 
         cnt[k] = (uint32_t)__popcll(m);
         rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         total += cnt[k];
-        if (f) atomicOr(&masks[(uint64_t)(id[k] >> 9) * ROWS + ((id[k] >> 6) & 7u)], 1ull << (id[k] & 63u));
     }
     if (total) {
         if (u.used + total > kUChunk) {                      // uniform: retire the chunk, take a new one
@@ -675,9 +685,8 @@ __global__ __launch_bounds__(256) void verify_kernel(
     const uint8_t *__restrict__ entries, const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, uint64_t magic,
     const CandRec *__restrict__ cand, const uint32_t *__restrict__ cand_used, const unsigned long long *cand_cursor,
     uint64_t cand_cap, kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used, unsigned long long *cursor,
-    uint64_t ulist_cap, unsigned long long *__restrict__ masks, unsigned long long *ctr)
+    uint64_t ulist_cap, unsigned long long *ctr)
 {
-    constexpr uint32_t ROWS = AA ? 1 : 6;
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4;
@@ -746,7 +755,6 @@ __global__ __launch_bounds__(256) void verify_kernel(
             }
             const unsigned long long m = __ballot(found);
             const uint32_t total = (uint32_t)__popcll(m);
-            if (found) atomicOr(&masks[(uint64_t)(r.id >> 9) * ROWS + ((r.id >> 6) & 7u)], 1ull << (r.id & 63u));
             if (total) {
                 const unsigned long long at = chunk_reserve(u, total, chunk_used, cursor, ulist_cap, lane);
                 if (at != ~0ull && found) {
@@ -773,7 +781,7 @@ __global__ __launch_bounds__(256) void overflow_probe_kernel(
     const uint8_t *__restrict__ entries, const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, uint64_t magic,
     const uint32_t *__restrict__ ovf_bucket, const uint64_t *__restrict__ ovf_ent, const uint32_t *__restrict__ ovf_cursor,
     uint32_t ovf_cap, uint32_t shift, kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used, unsigned long long *cursor, uint64_t ulist_cap,
-    unsigned long long *__restrict__ masks, unsigned long long *ctr)
+    unsigned long long *ctr)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(256) void overflow_probe_kernel(
         const uint32_t b = ovf_bucket[g];
         uint64_t e[1];
         e[0] = lane < (int)kGroup ? ovf_ent[(uint64_t)g * kGroup + lane] : kEntInvalid;
-        probe_entries<AA, 1, COUNTERS>(tab, b, shift, e, ulist, chunk_used, cursor, ulist_cap, masks, u, ctr_slots, ran_off, lane);
+        probe_entries<AA, 1, COUNTERS>(tab, b, shift, e, ulist, chunk_used, cursor, ulist_cap, u, ctr_slots, ran_off, lane);
     }
     if (lane == 0 && u.have && u.base + kUChunk <= ulist_cap) chunk_used[u.base / kUChunk] = u.used;
     flush_ran_off(ran_off, ctr, lane);
@@ -800,111 +808,15 @@ __global__ __launch_bounds__(256) void overflow_probe_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Ordered placement, per chunk of blocks [block_lo, block_lo + n_blocks).  A chunk starts and ends at sequence
-// boundaries, so its rows are the contiguous range [ROWS * block_lo, ROWS * (block_lo + n_blocks)) of the
-// container-major row order and its hits a contiguous range of hits[] that starts at *base (the hits of the chunks
-// before it; device memory, chained by chunk_base_kernel).  This lets chunk c be ordered while chunk c+1 is
-// still being scattered and probed.
-template <bool AA>
-__global__ void rows_from_masks_kernel(const BlockDesc *__restrict__ blocks, uint32_t block_lo, uint32_t n_blocks,
-                                       const unsigned long long *__restrict__ masks, uint32_t *__restrict__ counts)
-{
-    constexpr uint32_t ROWS = AA ? 1 : 6;
-    const uint64_t tl = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tl >= (uint64_t)n_blocks * ROWS) return;
-    const uint64_t t = (uint64_t)block_lo * ROWS + tl;
-    const uint32_t it = (uint32_t)(t / ROWS), r = (uint32_t)(t % ROWS);
-    const BlockDesc bd = blocks[it];
-    counts[row_index<AA>(bd, it, (int)r)] = (uint32_t)__popcll(masks[t]);
-}
-
+// A chunk of the batch starts and ends at sequence boundaries, so its rows are a contiguous range of the container-major
+// row order and its hits a contiguous range of hits[] that starts at *base (the hits of the chunks before it; device
+// memory, chained here).  This lets chunk c be ordered (kg_order.hpp) while chunk c+1 is still being scattered and probed.
 // base[1] = base[0] + *chunk_total; the last chunk also publishes the grand total
 __global__ void chunk_base_kernel(const uint64_t *chunk_total, uint64_t *base, uint64_t *grand_total)
 {
     const uint64_t b = base[0] + *chunk_total;
     base[1] = b;
     if (grand_total) *grand_total = b;
-}
-
-// One 24-byte record per (block,row): everything the placement of a hit needs, so that it costs one random line
-// per hit instead of three (block descriptor, mask, offset).
-struct RowInfo {
-    unsigned long long mask;     // hit lanes of the row
-    uint32_t off;                // index of the row's first hit in hits[]
-    uint32_t container;
-    int32_t pos0;                // from0InProt of lane 0's window
-    int32_t step;                // +1: positions ascend with the lane ('+' rows, proteins); -1: they descend ('-' rows)
-};
-static_assert(sizeof(RowInfo) == 24, "RowInfo must be 24 bytes");
-
-// offs[] holds the chunk-local exclusive prefix on entry and the global one on return
-template <bool AA>
-__global__ void row_info_kernel(const BlockDesc *__restrict__ blocks, uint32_t block_lo, uint32_t n_blocks,
-                                const unsigned long long *__restrict__ masks, uint32_t *__restrict__ offs,
-                                const uint64_t *__restrict__ base, RowInfo *__restrict__ info)
-{
-    constexpr uint32_t ROWS = AA ? 1 : 6;
-    const uint64_t tl = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tl >= (uint64_t)n_blocks * ROWS) return;
-    const uint64_t t = (uint64_t)block_lo * ROWS + tl;
-    const uint32_t it = (uint32_t)(t / ROWS), r = (uint32_t)(t % ROWS);
-    const BlockDesc bd = blocks[it];
-    const uint32_t row = row_index<AA>(bd, it, (int)r);
-    RowInfo ri;
-    ri.mask = masks[t];
-    ri.off = (uint32_t)*base + offs[row];
-    offs[row] = ri.off;
-    row_record_key<AA>(bd, (int)r, 0, &ri.container, &ri.pos0);
-    ri.step = (!AA && r >= 3) ? -1 : 1;
-    info[t] = ri;
-}
-
-// unordered list -> hits[] ordered by (container, from0InProt); one workgroup per reservation chunk of the list
-// (the grid covers the list's capacity; workgroups beyond the cursor leave)
-template <bool AA>
-__global__ __launch_bounds__(256) void place_unordered_kernel(const RowInfo *__restrict__ info,
-                                                              const kg_hit *__restrict__ ulist,
-                                                              const uint32_t *__restrict__ chunk_used,
-                                                              const unsigned long long *__restrict__ cursor, uint64_t ulist_cap,
-                                                              kg_hit *__restrict__ hits, uint64_t hits_cap)
-{
-    constexpr uint32_t ROWS = AA ? 1 : 6;
-    const uint32_t c = blockIdx.x;
-    const unsigned long long cur = *cursor;
-    if ((uint64_t)c >= (cur < ulist_cap ? cur : ulist_cap) / kUChunk) return;
-    const uint32_t used = chunk_used[c];
-    // kUChunk = 2 x 256: each thread places two records; both record loads, then both RowInfo loads, then the stores,
-    // so that a thread keeps two random lines in flight at every step
-    static_assert(kUChunk == 512, "place_unordered_kernel assumes two records per thread");
-    kg_hit h[2];
-    RowInfo ri[2];
-    bool act[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const uint32_t k = threadIdx.x + 256u * j;
-        act[j] = k < used;
-        if (act[j]) h[j] = ulist[(uint64_t)c * kUChunk + k];
-    }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        if (act[j]) {
-            const uint32_t id = h[j].container;
-            ri[j] = info[(uint64_t)(id >> 9) * ROWS + ((id >> 6) & 7u)];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        if (act[j]) {
-            const uint32_t ln = h[j].container & 63u;
-            // '+' rows ascend with the lane, '-' rows descend (see scan_kernel)
-            const unsigned long long before =
-                ri[j].step < 0 ? (ln == 63 ? 0ull : (ri[j].mask >> (ln + 1))) : (ri[j].mask & ((1ull << ln) - 1ull));
-            h[j].container = ri[j].container;
-            h[j].from0InProt = ri[j].pos0 + ri[j].step * (int32_t)ln;
-            const uint64_t dst = (uint64_t)ri[j].off + (uint32_t)__popcll(before);
-            if (dst < hits_cap) hits[dst] = h[j];       // only out of range when a list overflowed: that scan is re-run
-        }
-    }
 }
 
 }  // namespace kg

@@ -37,6 +37,14 @@ constexpr uint32_t kSubSlabs = KG_SUB_SLABS;       // entries per thread and til
 constexpr uint32_t kSubTile = kSubThreads * kSubSlabs;
 constexpr uint32_t kMaxSub = 64;            // sub-buckets per bucket (one lane each in the reservation step)
 
+// two consecutive entries with one 16-byte streaming load (p 16-byte aligned)
+typedef unsigned long long kg_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load_entry_pair(const uint64_t *p, uint64_t &a, uint64_t &b)
+{
+    const kg_u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const kg_u64x2 *>(p));
+    a = v.x; b = v.y;
+}
+
 // Work item = (bucket b, regions [part * rpi, (part + 1) * rpi) of it); items are drawn from one ticket counter in
 // bucket order, so that the workgroups of the grid work on a few buckets at a time and a sub-bucket's array is filled
 // by stores that follow each other closely (runs start where the previous one ended: partial lines meet in the L2).
@@ -65,18 +73,24 @@ __global__ __launch_bounds__(kSubThreads) void sub_scatter_kernel(
         uint32_t w = w_lo, o = 0;                          // next slab: region w, slots [o, o + kSubThreads)   (uniform)
         uint32_t f = w < w_hi ? min(fill[(uint64_t)b * n_regions + w], cap) : 0u;
         uint64_t en[kSubSlabs];
+        // (a slab = 2 * kSubThreads consecutive slots, two per thread in one 16-byte load: regions start on 128-byte lines
+        //  and hold a multiple of 16 slots)
+        static_assert(kSubSlabs % 2 == 0, "entries are loaded in pairs");
         auto load_tile = [&]() {
 #pragma unroll
-            for (uint32_t k = 0; k < kSubSlabs; k++) {
-                en[k] = kEntInvalid;
+            for (uint32_t k = 0; k < kSubSlabs; k += 2) {
+                en[k] = en[k + 1] = kEntInvalid;
                 while (w < w_hi && o >= f) {               // next region with entries left (uniform)
                     w++; o = 0;
                     f = w < w_hi ? min(fill[(uint64_t)b * n_regions + w], cap) : 0u;
                 }
                 if (w < w_hi) {
-                    const uint32_t i = o + tid;
-                    if (i < f) en[k] = __builtin_nontemporal_load(ent + ((uint64_t)b * n_regions + w) * cap + i);
-                    o += kSubThreads;
+                    const uint32_t i = o + 2u * tid;
+                    if (i < f) {
+                        load_entry_pair(ent + ((uint64_t)b * n_regions + w) * cap + i, en[k], en[k + 1]);
+                        if (i + 1u >= f) en[k + 1] = kEntInvalid;       // (bulk appends of the low-complexity pass leave odd fills)
+                    }
+                    o += 2u * kSubThreads;
                 }
             }
             while (w < w_hi && o >= f) {                   // (so that the loop ends with the item's last entry, not a tile later)
@@ -153,6 +167,11 @@ __global__ __launch_bounds__(kSubThreads) void sub_scatter_kernel(
 // K2.  Item it = (bucket << (shift - sshift)) | sub-bucket: tags [it << sshift, + 2^sshift + 16), entries
 // ent2[it * cap2 .. + min(cur2[it], cap2)).  Dynamic LDS: 2^sshift + 16 bytes.
 constexpr uint32_t kProbe2Threads = 512;
+#ifndef KG_INDEX_THREADS
+#define KG_INDEX_THREADS 1024
+#endif
+constexpr uint32_t kIndexThreads = KG_INDEX_THREADS;      // home-index probe: two workgroups (64 KiB of LDS each) fill a CU's 32 wave slots
+static_assert(kProbeN % 2 == 0, "entries are loaded in pairs");
 
 template <bool COUNTERS>
 __global__ __launch_bounds__(kProbe2Threads) void sub_probe_kernel(
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(kProbe2Threads) void sub_probe_kernel(
 // of the home slots) falls back to the generic walk (kWalkOn).  lookup_ran_off: a miss whose home slot lies in the
 // occupied run that ends at the end of the record stream (home >= tail_start) is a walk that the reference ends with
 // an EOFException (KGJ:799-802).  Item it, tile and entries as in sub_probe_kernel; dynamic LDS: 2 << sshift bytes.
-__global__ __launch_bounds__(kProbe2Threads) void sub_index_kernel(
+__global__ __launch_bounds__(kIndexThreads) void sub_index_kernel(
     const uint16_t *__restrict__ qidx, uint64_t n_idx, uint32_t exact /* every quotient < 31 */, uint32_t tail_start,
     const uint64_t *__restrict__ ent2,
     const uint32_t *__restrict__ cur2, uint32_t cap2, uint32_t n_items, uint32_t shift, uint32_t sshift, uint32_t *next_item /* zeroed */,
@@ -313,26 +332,31 @@ __global__ __launch_bounds__(kProbe2Threads) void sub_index_kernel(
         const uint64_t t0 = (uint64_t)it << sshift;     // first slot of the sub-bucket
         const uint32_t b = it >> (shift - sshift);
         const uint64_t *src = ent2 + (uint64_t)it * cap2;
-        uint64_t ev[N];
+        // entries in pairs (one 16-byte load): thread t takes entries 2t, 2t + 1 of every 2 * kIndexThreads (arrays start on
+        // 128-byte lines and hold a multiple of 16 slots: the pair behind an odd count is inside the array and ignored)
+        auto load_batch = [&](uint32_t c0, uint64_t (&dst)[N]) {
 #pragma unroll
-        for (int k = 0; k < N; k++) {
-            const uint32_t i = (uint32_t)k * kProbe2Threads + tid;
-            ev[k] = i < n ? __builtin_nontemporal_load(src + i) : kEntInvalid;
-        }
-        for (uint32_t c = tid * 8u; c < tile_slots; c += kProbe2Threads * 8u) {      // eight words = 16 bytes per load
+            for (int k = 0; k < N; k += 2) {
+                const uint32_t i = c0 + (uint32_t)k * kIndexThreads + 2u * tid;
+                dst[k] = dst[k + 1] = kEntInvalid;
+                if (i < n) {
+                    load_entry_pair(src + i, dst[k], dst[k + 1]);
+                    if (i + 1u >= n) dst[k + 1] = kEntInvalid;
+                }
+            }
+        };
+        uint64_t ev[N];
+        load_batch(0u, ev);
+        for (uint32_t c = tid * 8u; c < tile_slots; c += kIndexThreads * 8u) {      // eight words = 16 bytes per load
             uint4 v = make_uint4(0x7FFF7FFFu, 0x7FFF7FFFu, 0x7FFF7FFFu, 0x7FFF7FFFu);  // behind the index: no key
             const uint64_t at = t0 + c;
             if (at + 8u <= n_idx) v = *reinterpret_cast<const uint4 *>(qidx + at);
             *reinterpret_cast<uint4 *>(tile + 2u * c) = v;
         }
         __syncthreads();
-        for (uint32_t c0 = 0; c0 < n; c0 += kProbe2Threads * N) {
+        for (uint32_t c0 = 0; c0 < n; c0 += kIndexThreads * N) {
             uint64_t en[N];                             // the next batch, requested before this one is probed
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-                const uint32_t i = c0 + kProbe2Threads * N + (uint32_t)k * kProbe2Threads + tid;
-                en[k] = i < n ? __builtin_nontemporal_load(src + i) : kEntInvalid;
-            }
+            load_batch(c0 + kIndexThreads * N, en);
             uint32_t home[N], quo[N], candm = 0, walkm = 0;
 #pragma unroll
             for (int k = 0; k < N; k++) {

@@ -9,6 +9,7 @@
 #include "kg_aggregate.hpp"
 #include "kg_partition.hpp"
 #include "kg_partition2.hpp"
+#include "kg_order.hpp"
 
 #include <fcntl.h>
 #include <unistd.h>
@@ -176,7 +177,8 @@ struct kg_table {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // partitioned scan: tag pass of chunk c while chunk c+1 is scattered (stream)
     hipStream_t stream3 = nullptr;      // ... and while chunk c-1 is verified and placed
-    hipEvent_t pev[20] = {};            // [2c] chunk c scattered, [2c+1] chunk c tag-probed (c < 8); [16],[17],[18] fork / joins
+    hipEvent_t pev[32] = {};            // [2c] chunk c scattered, [2c+1] chunk c tag-probed (c < 8); [16],[17],[18] fork / joins;
+                                        // [20+c] chunk c verified
     bool own_entries = false;
     uint8_t *d_entries = nullptr;
     uint8_t *d_tags = nullptr;
@@ -191,6 +193,7 @@ struct kg_table {
     uint64_t occupied = 0;
     double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
     size_t scatter_lds[2] = {0, 0};  // dynamic LDS the scatter kernel (DNA / protein) has been allowed so far
+    size_t hist_lds = 48 * 1024;     // ... and the hit histogram kernel (kg_order.hpp)
     size_t probe2_lds[3] = {0, 0, 0};   // ... and the second-level probe kernels (tags without / with counters, home index)
     hipEvent_t ev[8] = {};
     // Pinned host words for the few counters a scan reads back (a hipMemcpyAsync to pageable memory blocks the host per
@@ -904,11 +907,15 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         const uint32_t ovf_cap = env_u32("KG_PART_OVF_GROUPS", (uint32_t)std::min<uint64_t>(1u << 23, std::max<uint64_t>(65536, n_regions_total * cap / 16 / 8)));
         uint64_t *d_ent = nullptr, *d_ovf_ent = nullptr;
         uint32_t *d_fill = nullptr, *d_ovf_bucket = nullptr, *d_next = nullptr, *d_ovfc = nullptr;
-        unsigned long long *d_masks = nullptr;
-        kg::RowInfo *d_info = nullptr;
+        kg::RowGeo *d_geo = nullptr;         // per row: container and position of its first window (kg_order.hpp)
         uint64_t *d_pc = nullptr;            // [0..7] hit-list cursors, [8..15] candidate cursors, [16..24] base, [32..39] chunk totals
-        uint64_t *d_partial_c = nullptr;
-        const size_t partial_stride = (size_t)(chunk_blocks * PER / kg::kScanChunk + 2);
+        // ordered placement (kg_order.hpp): groups of 2^gshift rows, at most kMaxGroups per chunk (8192 while 4096-row groups allow it)
+        uint32_t gshift = 10;
+        while (gshift < 12 && ((max_chunk * PER) >> gshift) + 2 > 8192) gshift++;
+        const uint32_t groups_stride = (uint32_t)(((max_chunk * PER) >> gshift) + 2);      // a chunk's rows start anywhere inside a group
+        if (groups_stride > kg::kMaxGroups) return fail(KG_ERR_LIMIT, "a chunk of the batch holds more than 2^26 window rows");
+        uint32_t *d_ghist = nullptr, *d_gbase = nullptr, *d_gcur1 = nullptr, *d_gcur2 = nullptr;
+        kg_hit *d_sortA = nullptr, *d_sortB = nullptr;
         if ((rc = sc.get(&d_ent, (size_t)(n_regions_total * cap * n_chunks_p)))) return rc;
         if ((rc = sc.get(&d_fill, (size_t)n_regions_total * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_ovf_ent, (size_t)ovf_cap * kg::kGroup * n_chunks_p))) return rc;
@@ -918,10 +925,21 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if ((rc = sc.get(&d_ovfc, 8 * kMaxChunks))) return rc;       // per chunk: [0] overflow groups, [1] low-complexity blocks
         uint32_t *d_lowc = nullptr;                                    // block numbers set aside by the scatter pass
         if ((rc = sc.get(&d_lowc, (size_t)nblocks + 1))) return rc;
-        if ((rc = sc.get(&d_masks, (size_t)n_rows))) return rc;
-        if ((rc = sc.get(&d_info, (size_t)n_rows))) return rc;
+        if ((rc = sc.get(&d_geo, (size_t)n_rows))) return rc;
+        if ((rc = sc.get(&d_ghist, (size_t)groups_stride * n_chunks_p))) return rc;
+        if ((rc = sc.get(&d_gbase, (size_t)(groups_stride + 1) * n_chunks_p))) return rc;
+        if ((rc = sc.get(&d_gcur1, (size_t)(kg::kHDigits + 1) * n_chunks_p))) return rc;
+        if ((rc = sc.get(&d_gcur2, (size_t)groups_stride * n_chunks_p))) return rc;
+        if (groups_stride * 4u > t->hist_lds) {
+            HIP_TRY(hipFuncSetAttribute((const void *)kg::hit_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(groups_stride * 4u)));
+            t->hist_lds = groups_stride * 4u;
+        }
+        {   // the rows' geometry records: they depend on the batch only, not on the hits
+            const uint64_t nthr = nblocks * PER;
+            hipLaunchKernelGGL((kg::row_geo_kernel<AA>), dim3((uint32_t)((nthr + 255) / 256)), dim3(256), 0, t->stream, d_blocks,
+                               (uint32_t)nblocks, d_geo);
+        }
         if ((rc = sc.get(&d_pc, 48))) return rc;
-        if ((rc = sc.get(&d_partial_c, partial_stride * n_chunks_p))) return rc;
         unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
         // Second partition level (kg_partition2.hpp): the entries of a bucket are cut once more, by sub-bucket of 2^sshift
         // slots, and probed against tags held in LDS.  KG_PART_LEVELS: 1 = tag pass out of the L2 (bucket_tag_kernel),
@@ -986,9 +1004,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         // back to the cache with the rest of the scratch once the streams are idle (Scratch's destructor runs later)
         struct ListGuard {
             Scratch &sc;
-            void **slot[4];
+            void **slot[6];
             ~ListGuard() { for (void **q : slot) if (*q) { sc.adopt(*q); *q = nullptr; } }
-        } list_guard{sc, {(void **)&d_ulist, (void **)&d_cused, (void **)&d_cand, (void **)&d_candused}};
+        } list_guard{sc, {(void **)&d_ulist, (void **)&d_cused, (void **)&d_cand, (void **)&d_candused, (void **)&d_sortA, (void **)&d_sortB}};
         bool too_skewed = false;
         const uint32_t grab_unit = 256u * kg::kProbeN;
         const uint32_t probe_grab = (std::max(env_u32("KG_PROBE_GRAB", cap), grab_unit) + grab_unit - 1) / grab_unit * grab_unit;
@@ -1002,6 +1020,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             if ((rc = dalloc(t, (void **)&d_cused, cused_stride * n_chunks_p * 4))) return rc;
             if ((rc = dalloc(t, (void **)&d_cand, ccap * n_chunks_p * sizeof(kg::CandRec)))) return rc;
             if ((rc = dalloc(t, (void **)&d_candused, candused_stride * n_chunks_p * 4))) return rc;
+            if ((rc = dalloc(t, (void **)&d_sortA, ucap * n_chunks_p * sizeof(kg_hit)))) return rc;
+            if ((rc = dalloc(t, (void **)&d_sortB, ucap * n_chunks_p * sizeof(kg_hit)))) return rc;
             {   // one launch for all clears (d_totals: totals, counters and flags of a re-run start over)
                 kg::ClearList cl;
                 cl.n = 7;
@@ -1011,7 +1031,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 cl.p[3] = reinterpret_cast<uint32_t *>(d_totals); cl.words[3] = 16;
                 cl.p[4] = d_ovfc; cl.words[4] = 8 * kMaxChunks;
                 cl.p[5] = d_next; cl.words[5] = (uint64_t)next_stride * n_chunks_p;
-                cl.p[6] = reinterpret_cast<uint32_t *>(d_masks); cl.words[6] = (uint64_t)n_rows * 2;
+                cl.p[6] = d_ghist; cl.words[6] = (uint64_t)groups_stride * n_chunks_p;
                 cl.p[7] = nullptr; cl.words[7] = 0;
                 if (levels == 2) { cl.n = 8; cl.p[7] = d_cur2; cl.words[7] = n_sub_total * n_chunks_p; }
                 const uint64_t most = std::max<uint64_t>(cl.words[6], 1) / 4;
@@ -1033,7 +1053,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 uint32_t *cused_c = d_cused + c * cused_stride, *candused_c = d_candused + c * candused_stride;
                 kg::CandRec *cand_c = d_cand + (uint64_t)c * ccap;
                 unsigned long long *ucur_c = (unsigned long long *)(d_pc + c), *ccur_c = (unsigned long long *)(d_pc + 8 + c);
-                uint64_t *base_c = d_pc + 16 + c, *ctot_c = d_pc + 32 + c;
+                (void)0;
                 if (!seq_uploaded && (rc = upload(offsets[cseq[c]], offsets[cseq[c + 1]]))) return rc;
                 hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
                                    d_blocks, lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
@@ -1051,7 +1071,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                                    ovf_bucket_c, ovf_ent_c, d_ctr);
 #define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
                     candused_c, ccur_c, ccap, d_ctr
-#define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_masks, d_ctr
+#define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_ctr
                 if (levels == 2) {
                     uint64_t *ent2_c = d_ent2 + (uint64_t)c * n_sub_total * cap2;
                     uint32_t *cur2_c = d_cur2 + (uint64_t)c * n_sub_total;
@@ -1066,7 +1086,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                     const uint32_t grid2 = std::min(n_items2, std::max(1u, env_u32("KG_PROBE2_GRID", 256u * per_cu)));
 #define KG_TAG2_ARGS t->d_tags, t->limit, ent2_c, cur2_c, cap2, n_items2, part_shift, sshift, next_c + 64, cand_c, candused_c, ccur_c, ccap, d_ctr
                     if (use_qidx)
-                        hipLaunchKernelGGL(kg::sub_index_kernel, dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, t->d_qidx, t->n_qidx,
+                        hipLaunchKernelGGL(kg::sub_index_kernel, dim3(grid2), dim3(kg::kIndexThreads), tile_lds, s2, t->d_qidx, t->n_qidx,
                                            t->qidx_exact ? 1u : 0u, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent2_c, cur2_c, cap2, n_items2, part_shift,
                                            sshift, next_c + 64, cand_c, candused_c, ccur_c, ccap, d_ctr);
                     else if (counters) hipLaunchKernelGGL((kg::sub_probe_kernel<true>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
@@ -1089,22 +1109,50 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 }
 #undef KG_TAG_ARGS
 #undef KG_ULIST_ARGS
-                // ordered placement of the chunk's hits
-                const uint64_t rows_c = (uint64_t)nb * PER, row_lo = (uint64_t)lo * PER;
-                const uint32_t rgrid = (uint32_t)((rows_c + 255) / 256);
-                hipLaunchKernelGGL((kg::rows_from_masks_kernel<AA>), dim3(rgrid), dim3(256), 0, s3, d_blocks, lo, nb, d_masks, d_counts);
-                if ((rc = prefix_sum(t, d_counts + row_lo, rows_c, d_offs + row_lo, d_partial_c + c * partial_stride, ctot_c, s3))) return rc;
-                hipLaunchKernelGGL(kg::chunk_base_kernel, dim3(1), dim3(1), 0, s3, ctot_c, base_c,
-                                   c + 1 == n_chunks_p ? d_totals : (uint64_t *)nullptr);
-                hipLaunchKernelGGL((kg::row_info_kernel<AA>), dim3(rgrid), dim3(256), 0, s3, d_blocks, lo, nb, d_masks, d_offs, base_c,
-                                   d_info);
-                hipLaunchKernelGGL((kg::place_unordered_kernel<AA>), dim3((uint32_t)(ucap / kg::kUChunk)), dim3(256), 0, s3, d_info,
-                                   ulist_c, cused_c, ucur_c, ucap, res->d_hits, hits_cap);
+                HIP_TRY(hipEventRecord(t->pev[20 + c], s3));                // chunk c verified
                 HIP_TRY(hipGetLastError());
                 if (c + 1 == n_chunks_p) HIP_TRY(hipEventRecord(t->ev[5], t->stream));   // all chunks scattered
             }
 #undef KG_PROBE_ARGS
             seq_uploaded = true;
+            // Ordered placement (kg_order.hpp), chunk by chunk on the scatter stream, i.e. behind the LAST scatter pass and
+            // beside the tag passes that are still running: its partition workgroups hold 51 KB of LDS and eight wave slots
+            // each, and started beside a scatter pass (105 KB and 16 wave slots of every CU) the two starve each other --
+            // chunk 0's two partition passes took 2.2 + 4.3 ms instead of 0.15 + 0.55 and the scatter pass beside them 7.8 ms
+            // instead of 2 (profiles/r03_ordering.md).  (A fourth stream shares a hardware queue with the third.)
+            for (uint32_t c = 0; c < n_chunks_p; c++) {
+                const uint32_t lo = (uint32_t)clo[c], nb = (uint32_t)(clo[c + 1] - clo[c]);
+                kg_hit *ulist_c = d_ulist + (uint64_t)c * ucap;
+                uint32_t *cused_c = d_cused + c * cused_stride;
+                unsigned long long *ucur_c = (unsigned long long *)(d_pc + c);
+                uint64_t *base_c = d_pc + 16 + c, *ctot_c = d_pc + 32 + c;
+                hipStream_t s3 = t->stream;
+                HIP_TRY(hipStreamWaitEvent(s3, t->pev[20 + c], 0));
+                // group histogram -> group starts -> two partition passes by key range -> ranking inside each group of rows
+                {
+                    const uint64_t row_lo = (uint64_t)lo * PER, row_hi = row_lo + (uint64_t)nb * PER;
+                    const uint32_t g0 = (uint32_t)(row_lo >> gshift);
+                    const uint32_t n_groups = nb ? (uint32_t)(((row_hi - 1) >> gshift) - g0 + 1) : 1u;
+                    uint32_t *ghist_c = d_ghist + (size_t)c * groups_stride, *gbase_c = d_gbase + (size_t)c * (groups_stride + 1);
+                    uint32_t *gcur1_c = d_gcur1 + (size_t)c * (kg::kHDigits + 1), *gcur2_c = d_gcur2 + (size_t)c * groups_stride;
+                    kg_hit *sortA_c = d_sortA + (uint64_t)c * ucap, *sortB_c = d_sortB + (uint64_t)c * ucap;
+                    const uint32_t ogrid = env_u32("KG_ORDER_GRID", 256u * 3u);
+                    hipLaunchKernelGGL(kg::hit_hist_kernel, dim3(ogrid), dim3(kg::kHThreads), (size_t)n_groups * 4, s3, ulist_c, cused_c, ucur_c, ucap,
+                                       g0, 6u + gshift, n_groups, ghist_c);
+                    hipLaunchKernelGGL(kg::group_scan_kernel, dim3(1), dim3(1024), 0, s3, ghist_c, n_groups, gbase_c, gcur1_c, gcur2_c, ctot_c);
+                    hipLaunchKernelGGL(kg::chunk_base_kernel, dim3(1), dim3(1), 0, s3, ctot_c, base_c,
+                                       c + 1 == n_chunks_p ? d_totals : (uint64_t *)nullptr);
+                    hipLaunchKernelGGL((kg::hit_partition_kernel<true>), dim3(ogrid), dim3(kg::kHThreads), 0, s3, ulist_c, cused_c, ucur_c, ucap,
+                                       gbase_c, n_groups, g0, 6u + gshift, gcur1_c, sortA_c, ucap);
+                    hipLaunchKernelGGL((kg::hit_partition_kernel<false>), dim3(ogrid), dim3(kg::kHThreads), 0, s3, sortA_c, cused_c, ucur_c, ucap,
+                                       gbase_c, n_groups, g0, 6u + gshift, gcur2_c, sortB_c, ucap);
+                    hipLaunchKernelGGL((kg::group_place_kernel<AA>), dim3(std::min(n_groups, 256u * 8u)), dim3(kg::kHThreads), (size_t)12 << gshift, s3,
+                                       sortB_c, gbase_c, n_groups, g0, gshift, (uint32_t)row_lo, (uint32_t)row_hi, d_geo, base_c, res->d_hits,
+                                       hits_cap, d_offs);
+                }
+                HIP_TRY(hipGetLastError());
+            }
+
             HIP_TRY(hipEventRecord(t->pev[17], t->stream2));              // join
             HIP_TRY(hipStreamWaitEvent(t->stream, t->pev[17], 0));
             HIP_TRY(hipEventRecord(t->pev[18], t->stream3));
