@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--no-overlap-exchange", dest="overlap_exchange", action="store_false", default=True,
                     help="N > 1: finish every step's exchange before the next scan starts (default: the record buffers of step i "
                          "travel while step i + 1 is scanned)")
+    ap.add_argument("--sink-share", type=float, default=-1.0,
+                    help="N > 1, strong scaling: rank 0's share of the contigs relative to an equal share (rank 0 also receives every "
+                         "rank's records and puts the hit records in global order: ~1 ms per step for 36.7 M records, tools/restore_time.py). "
+                         "Default: 1 - 0.15 * N / 8 when the hit records are gathered, else 1")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     ap.add_argument("--strategy", choices=["auto", "direct", "partitioned"], default="auto",
                     help="scan strategy of the library (KG_PARTITION): auto picks partitioned probing for large inputs")
@@ -125,12 +129,14 @@ def main():
     all_lens = synth.contig_mix_lengths(args.total_bp, 301)
     all_off = synth.offsets_of(all_lens)
     strong = args.scaling == "strong" or world == 1
+    sink_share = 1.0
     if world == 1:
         mine, n_total = np.arange(len(all_lens), dtype=np.int64), len(all_lens)
         lens, seq = all_lens, synth.random_dna(int(all_off[-1]), 302, dev)
     elif strong:
         # the one contig list, whole contigs balanced over the ranks; a contig has the bases it has in the unsharded batch
-        mine, n_total = kd.shard_sequences(all_lens, world)[rank], len(all_lens)
+        sink_share = args.sink_share if args.sink_share > 0 else (1.0 - 0.15 * world / 8.0 if args.gather_hits else 1.0)
+        mine, n_total = kd.shard_sequences(all_lens, world, [sink_share] + [1.0] * (world - 1))[rank], len(all_lens)
         lens = all_lens[mine]
         seq = synth.random_dna_at(all_off[mine], lens, 302, dev)
     else:
@@ -278,6 +284,7 @@ def main():
                            hits_probe, note="two extra steps after the timed region, hit records (24 B each) gathered to rank 0 "
                                             "too and put in global (container, from0InProt) order on the device",
                            hit_bytes_all_ranks=int(hits_all) * 24)),
+                       "sink_share": (sink_share if world > 1 and strong else None),
                        "parallelism": "contig shards x%d, table replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -206,6 +206,15 @@ const void    *kg_result_device_container_hit_start(const kg_result *r);   /* in
 const void    *kg_result_device_container_call_start(const kg_result *r);  /* int64[n_containers + 1], NULL with KG_F_SKIP_AGGREGATE */
 void kg_result_free(kg_result *r);
 
+/* ---- multi-GPU exchange helper (no counterpart in the reference, which is one process; used by the host layer that
+ *      gathers per-rank hit buffers, kmergutsjava_amd/distributed.py).  The n_hits records at d_src are ordered by a shard's
+ *      LOCAL containers; the records of local sequence k are d_src[d_seq_first[k] .. d_seq_first[k + 1]) (d_seq_first has
+ *      n_seqs + 1 entries) and go to d_dst[d_dst_first[k] ..) with d_container_shift[k] added to their container field.
+ *      All pointers are device memory; the copy is enqueued on `stream` (a hipStream_t, NULL = the null stream) and not
+ *      waited for. ---- */
+int kg_restore_hits_device(int device, const kg_hit *d_src, int64_t n_hits, const int64_t *d_seq_first, int64_t n_seqs,
+                           const int64_t *d_dst_first, const int32_t *d_container_shift, kg_hit *d_dst, void *stream);
+
 const char *kg_last_error(void);
 /* "libkmerguts_hip <version> gfx950" */
 const char *kg_version(void);

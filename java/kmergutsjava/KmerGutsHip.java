@@ -85,6 +85,8 @@ public interface KmerGutsHip extends Library {
     Pointer kg_result_device_container_hit_start(Pointer result);
     Pointer kg_result_device_container_call_start(Pointer result);
     void kg_result_free(Pointer result);
+    int kg_restore_hits_device(int device, Pointer dSrc, long nHits, Pointer dSeqFirst, long nSeqs, Pointer dDstFirst,
+                               Pointer dContainerShift, Pointer dDst, Pointer stream);
 
     String kg_last_error();
     String kg_version();

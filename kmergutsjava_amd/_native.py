@@ -26,7 +26,8 @@ EXPORTS = (
     "kg_scan", "kg_scan_device", "kg_aggregate_hits", "kg_process_set_of_hits", "kg_result_stats", "kg_result_hits", "kg_result_container_hit_start",
     "kg_result_calls", "kg_result_container_call_start", "kg_result_otu", "kg_result_hit_events",
     "kg_result_container_tail_events", "kg_result_copy_hits", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu",
-    "kg_result_device_container_hit_start", "kg_result_device_container_call_start", "kg_result_free", "kg_last_error", "kg_version",
+    "kg_result_device_container_hit_start", "kg_result_device_container_call_start", "kg_result_free", "kg_restore_hits_device",
+    "kg_last_error", "kg_version",
 )
 
 # event bits (include/kmerguts_hip.h KG_EV_*)
@@ -113,6 +114,7 @@ def load() -> C.CDLL:
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = vp
     lib.kg_result_copy_hits.argtypes = [vp, C.c_int64, C.c_int64, vp]
+    lib.kg_restore_hits_device.argtypes = [C.c_int, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp]
     lib.kg_result_free.argtypes = [vp]
     lib.kg_result_free.restype = None
     lib.kg_last_error.restype = C.c_char_p

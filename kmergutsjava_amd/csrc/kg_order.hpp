@@ -315,4 +315,44 @@ __global__ __launch_bounds__(kHThreads) void group_place_kernel(const kg_hit *__
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Multi-GPU exchange (kmergutsjava_amd/distributed.py): the hit records a rank sends are ordered by ITS containers; on the
+// gathering rank the records of local sequence k (one contiguous piece: a sequence's containers are adjacent) move to
+// dst_first[k] .. with container += container_shift[k].  A segmented copy: one binary search per record over the local
+// sequence starts (L2-resident), 24 bytes in, 24 bytes out, both coalesced.
+__global__ __launch_bounds__(256) void restore_hits_kernel(const kg_hit *__restrict__ src, uint64_t n_hits, const int64_t *__restrict__ seq_first,
+                                                           uint64_t n_seqs, const int64_t *__restrict__ dst_first,
+                                                           const int32_t *__restrict__ container_shift, kg_hit *__restrict__ dst)
+{
+    // a workgroup takes 1024 consecutive records at a time; the sequence of the first one is found by ONE binary search per
+    // tile, every thread then steps forward from there (sequences are thousands of records long; short reads: a few steps)
+    __shared__ uint64_t k_first;
+    constexpr uint64_t kTile = 1024;
+    const uint64_t n_tiles = (n_hits + kTile - 1) / kTile;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint64_t i0 = tile * kTile;
+            uint64_t lo = 0, hi = n_seqs;                   // largest k with seq_first[k] <= i0  (seq_first[n_seqs] == n_hits > i0)
+            while (hi - lo > 1) {
+                const uint64_t mid = lo + (hi - lo) / 2;
+                if ((uint64_t)seq_first[mid] <= i0) lo = mid; else hi = mid;
+            }
+            k_first = lo;
+        }
+        __syncthreads();
+        uint64_t k = k_first;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t i = tile * kTile + (uint64_t)j * 256 + threadIdx.x;
+            if (i < n_hits) {
+                while (k + 1 < n_seqs && (uint64_t)seq_first[k + 1] <= i) k++;
+                kg_hit h = src[i];
+                h.container += (uint32_t)container_shift[k];
+                dst[(uint64_t)dst_first[k] + (i - (uint64_t)seq_first[k])] = h;
+            }
+        }
+    }
+}
+
 }  // namespace kg

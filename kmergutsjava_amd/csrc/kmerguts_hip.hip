@@ -1578,6 +1578,20 @@ int64_t kg_table_live_device_bytes(kg_table *t)
     return t ? (int64_t)t->cache.live_bytes() : 0;
 }
 
+int kg_restore_hits_device(int device, const kg_hit *d_src, int64_t n_hits, const int64_t *d_seq_first, int64_t n_seqs,
+                           const int64_t *d_dst_first, const int32_t *d_container_shift, kg_hit *d_dst, void *stream)
+{
+    if (n_hits < 0 || n_seqs < 0) return fail(KG_ERR_ARG, "negative count");
+    if (n_hits == 0) return KG_OK;
+    if (!d_src || !d_seq_first || !d_dst_first || !d_container_shift || !d_dst || n_seqs == 0) return fail(KG_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t grid = (uint32_t)std::min<int64_t>((n_hits + 1023) / 1024, 256 * 16);
+    hipLaunchKernelGGL(kg::restore_hits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_src, (uint64_t)n_hits, d_seq_first,
+                       (uint64_t)n_seqs, d_dst_first, d_container_shift, d_dst);
+    HIP_TRY(hipGetLastError());
+    return KG_OK;
+}
+
 const void *kg_result_device_hits(const kg_result *r) { return r ? r->d_hits : nullptr; }
 const void *kg_result_device_calls(const kg_result *r) { return r ? r->d_calls : nullptr; }
 const void *kg_result_device_otu(const kg_result *r) { return r ? r->d_otu : nullptr; }

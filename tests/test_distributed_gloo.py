@@ -79,3 +79,8 @@ def test_shard_balance():
         loads = np.array([lens[i].sum() for i in sh])
         assert loads.max() / loads.mean() < 1.05, (w, loads)
         assert sum(len(i) for i in sh) == len(lens)
+        # the gathering rank can be given a smaller share
+        sh = kd.shard_sequences(lens, w, [0.8] + [1.0] * (w - 1))
+        loads = np.array([lens[i].sum() for i in sh], dtype=np.float64)
+        assert abs(loads[0] / loads[1:].mean() - 0.8) < 0.03 and loads[1:].max() / loads[1:].mean() < 1.05, (w, loads)
+        assert sorted(np.concatenate(sh).tolist()) == list(range(len(lens)))

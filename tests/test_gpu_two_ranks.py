@@ -52,3 +52,45 @@ def test_bench_self_launch_two_ranks(gather, overlap):
     assert cfg["hits_gathered_rank0"] == (cfg["hits_all_ranks"] if gather else None)      # every rank's hits reached rank 0
     assert (cfg["hits_gather_probe"] is None) == gather
     assert 0 < line["roofline"]["frac_step"] <= line["roofline"]["frac"] * 1.05
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_restore_hits_on_the_device_equals_the_unsharded_order(world):
+    """What rank 0 does with the gathered hit buffers on the RCCL path (device tensors): distributed.restore_hits through
+    the library's segmented-copy kernel (kg_restore_hits_device).  One process: a batch is scanned once, its hit records
+    are cut into the buffers the `world` ranks would send (whole contigs, LPT shards, containers renumbered locally), and
+    the restored array must be the unsharded one, record for record."""
+    import numpy as np
+    import torch
+    from kmergutsjava_amd import distributed as kd, hotpath, synth
+    dev = torch.device("cuda", 0)
+    rec, placed, keys = synth.random_table(5_000_011, 0.5, 202, dev)
+    lens = synth.contig_mix_lengths(30_000_000, 301)
+    lens[3] = 0                                                    # an empty sequence and one shorter than a window
+    lens[7] = 11
+    off = synth.offsets_of(lens)
+    seq = synth.random_dna(int(off[-1]), 302, dev)
+    torch.cuda.synchronize()
+    per = 6
+    with hotpath.SignatureTable.from_device_ptr(rec.data_ptr(), 5_000_011, 0, keepalive=rec) as tab:
+        with tab.scan(None, off, hotpath.Params(), device_ptr=seq.data_ptr()) as r:
+            hits = r.device_view("hits").clone().view(torch.int32).view(-1, 6)
+            chs = r.device_view("container_hit_start").clone()
+    assert hits.shape[0] > 2000
+    hb, cb, ib = [], [], []
+    for idx in kd.shard_sequences(lens, world):
+        it = torch.from_numpy(idx).to(dev)
+        lo, hi = chs[it * per], chs[it * per + per]
+        cnt = (chs[1:] - chs[:-1]).view(-1, per)[it].reshape(-1)
+        loc_chs = torch.zeros(len(idx) * per + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(cnt, 0, out=loc_chs[1:])
+        h = torch.cat([hits[int(a):int(b)] for a, b in zip(lo.tolist(), hi.tolist())]).clone()
+        shift = torch.repeat_interleave(((torch.arange(len(idx), device=dev) - it) * per).to(torch.int32), hi - lo, output_size=h.shape[0])
+        h[:, 0] += shift
+        hb.append(h.reshape(-1).view(torch.uint8)); cb.append(loc_chs); ib.append(it)
+    out, starts = kd.restore_hits(hb, cb, ib, len(lens), per)
+    torch.cuda.synchronize()
+    assert torch.equal(out, hits) and torch.equal(starts, chs)
+    # the same through the host formulation (what the gloo tests run)
+    out_c, starts_c = kd.restore_hits([x.cpu() for x in hb], [x.cpu() for x in cb], [x.cpu() for x in ib], len(lens), per)
+    assert torch.equal(out_c, hits.cpu()) and torch.equal(starts_c, chs.cpu())

@@ -16,7 +16,7 @@ f, w = agg(R + "/pmc_fetch/runc/*_counter_collection.csv"), agg(R + "/pmc_write/
 q, h = agg(R + "/pmc_rdreq/runc/*_counter_collection.csv"), agg(R + "/pmc_hit/runc/*_counter_collection.csv")
 bench = json.load(open(R + "/pmc_fetch.json"))
 strategy = bench["roofline"]["strategy"]
-scan_kernels = [k for k in f if any(x in k for x in (("part_scatter", "bucket_tag", "verify_kernel", "overflow_probe", "rows_from_masks", "row_info", "place_unordered") if strategy == "partitioned" else ("scan_kernel<false, false",)))]
+scan_kernels = [k for k in f if any(x in k for x in (("part_scatter", "bucket_tag", "sub_scatter", "sub_probe", "sub_index", "verify_kernel", "overflow_probe", "row_geo", "hit_hist", "group_scan", "hit_partition", "group_place", "lowc_blocks", "chunk_base") if strategy == "partitioned" else ("scan_kernel<false, false",)))]
 per_kernel = {}
 tot_fetch = tot_write = 0.0
 steps = 1      # the PMC runs use --steps 1 --warmup 0 plus the counters launch: take the launches of the LAST scan
