@@ -645,6 +645,10 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                     }
                 }
             }
+            // (Resolving the undecided windows here with a second tag load -- 27 M of the 65 M candidates per Gbp, each of which
+            //  costs the verify pass a random tag line -- was built and measured in round 3: verify 1.84 -> 1.55 ms alone, but
+            //  this kernel, the stage's critical chain, 3.9 -> 4.1 ms per chunk beside the scatter pass: stage 20.3 -> 20.8 ms.
+            //  profiles/r03_experiments.md.)
             // candidates -> list
             uint32_t cnt[N], rank[N], total = 0;
 #pragma unroll

@@ -934,11 +934,6 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             HIP_TRY(hipFuncSetAttribute((const void *)kg::hit_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(groups_stride * 4u)));
             t->hist_lds = groups_stride * 4u;
         }
-        {   // the rows' geometry records: they depend on the batch only, not on the hits
-            const uint64_t nthr = nblocks * PER;
-            hipLaunchKernelGGL((kg::row_geo_kernel<AA>), dim3((uint32_t)((nthr + 255) / 256)), dim3(256), 0, t->stream, d_blocks,
-                               (uint32_t)nblocks, d_geo);
-        }
         if ((rc = sc.get(&d_pc, 48))) return rc;
         unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
         // Second partition level (kg_partition2.hpp): the entries of a bucket are cut once more, by sub-bucket of 2^sshift
@@ -1041,6 +1036,12 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             HIP_TRY(hipEventRecord(t->pev[16], t->stream));               // fork: stream2 starts behind the clears
             HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[16], 0));
             HIP_TRY(hipStreamWaitEvent(t->stream3, t->pev[16], 0));
+            {   // the rows' geometry records (kg_order.hpp): they depend on the batch only, and the verify stream has nothing to do
+                // until the first chunk is scattered and probed
+                const uint64_t nthr = nblocks * PER;
+                hipLaunchKernelGGL((kg::row_geo_kernel<AA>), dim3((uint32_t)((nthr + 255) / 256)), dim3(256), 0, t->stream3, d_blocks,
+                                   (uint32_t)nblocks, d_geo);
+            }
 #define KG_PROBE_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic
             for (uint32_t c = 0; c < n_chunks_p; c++) {
                 const uint32_t lo = (uint32_t)clo[c], nb = (uint32_t)(clo[c + 1] - clo[c]);
