@@ -332,8 +332,8 @@ __global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
 // one piece (padded to whole groups with fillers; regions are filled through fill[] with global atomics now -- the
 // scatter workgroups have published them), or to the overflow list when the region is full; what is left goes in
 // single entries.  Regions are picked by block number, so a long run spreads over all of a bucket's regions.
-constexpr int kLowcWaves = 1;     // one wave per workgroup: 4.9 KB of LDS, so that the (usually idle) kernel finds room on a CU
-                                  // whose LDS a resident scatter workgroup has taken all but 7 KB of
+constexpr int kLowcWaves = 4;     // 3.4 KB of LDS per workgroup since the byte encode (0.7 KB per wave): the (usually idle) kernel
+                                  // still finds room on a CU whose LDS a resident scatter workgroup has taken 105 KB of
 template <bool AA>
 __global__ __launch_bounds__(64 * kLowcWaves) void lowc_blocks_kernel(
     const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, const uint32_t *__restrict__ lowc_cursor,

@@ -985,6 +985,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         // workgroups (profiles/r02_pipeline.md: 20.8 -> 20.4 ms per Gbp)
         const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 4u) & ~7u;
         const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
+        // The two kernels that usually find nothing to do (no low-complexity block set aside, no overflow group) sit on the
+        // stage's critical chain -- in front of every tag pass and behind every verify pass -- and beside the other passes a
+        // grid of 2048 / 1024 workgroups takes 0.1 / 0.35 ms just to be scheduled and leave (profiles/r03_kernel_stats.csv);
+        // one workgroup per CU leaves in microseconds and is still the whole chip when there is work.
+        const uint32_t lowc_grid = env_u32("KG_LOWC_GRID", 256u), ovf_grid = env_u32("KG_OVF_GRID", 256u);
         // per-chunk lists: hits (unordered) and candidates = fingerprint matches (hits + ~0.4 % of the probes) + the
         // ~2 % of the probes whose first tag window decides nothing
         const uint64_t list_slack = (uint64_t)(std::max(probe_grid, verify_grid) + 64) * 4 * kg::kUChunk + 4096;
@@ -1067,7 +1072,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 // 4.9 KB of LDS fit beside a resident scatter workgroup (153 KB of a CU's 160): with four-wave workgroups
                 // (15.8 KB) the kernel -- and the tag pass behind it -- waited for the NEXT chunk's scatter pass to leave
                 // the CUs (profiles/r02_pipeline.md).
-                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(2048 / kg::kLowcWaves), dim3(64 * kg::kLowcWaves), 0, s2, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
+                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(lowc_grid), dim3(64 * kg::kLowcWaves), 0, s2, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
                                    t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
                                    ovf_bucket_c, ovf_ent_c, d_ctr);
 #define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
@@ -1100,12 +1105,12 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 if (counters) {
                     hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, s3, KG_PROBE_ARGS, cand_c,
                                        candused_c, ccur_c, ccap, KG_ULIST_ARGS);
-                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(1024), dim3(256), 0, s3, KG_PROBE_ARGS,
+                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(ovf_grid), dim3(256), 0, s3, KG_PROBE_ARGS,
                                        ovf_bucket_c, ovf_ent_c, ovfc_c, ovf_cap, part_shift, KG_ULIST_ARGS);
                 } else {
                     hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, s3, KG_PROBE_ARGS, cand_c,
                                        candused_c, ccur_c, ccap, KG_ULIST_ARGS);
-                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(1024), dim3(256), 0, s3, KG_PROBE_ARGS,
+                    hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(ovf_grid), dim3(256), 0, s3, KG_PROBE_ARGS,
                                        ovf_bucket_c, ovf_ent_c, ovfc_c, ovf_cap, part_shift, KG_ULIST_ARGS);
                 }
 #undef KG_TAG_ARGS
