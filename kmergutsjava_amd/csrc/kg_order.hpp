@@ -220,13 +220,18 @@ __global__ __launch_bounds__(kHThreads) void hit_partition_kernel(const kg_hit *
                     stage[sbase[d] + (d >= 64 ? first_half : 0u) + (dr[k] & 0xFFFFu)] = rec[k];
                 }
             __syncthreads();
+            // a digit's run leaves as a flat stream of 8-byte words (three per record): consecutive lanes, consecutive words, so
+            // every store instruction covers whole lines (record-wise 24-byte stores wrote every line of a run three times in
+            // thirds and the partition passes' WRITE_SIZE was twice their data)
+            const uint64_t *stage64 = reinterpret_cast<const uint64_t *>(stage);
+            uint64_t *out64 = reinterpret_cast<uint64_t *>(out);
             for (uint32_t d = wave; d < kHDigits; d += kHThreads / 64u) {
                 const uint32_t n = cnt[d];
                 if (n == 0) continue;
                 const uint32_t s0 = sbase[d] + (d >= 64 ? first_half : 0u);
                 const uint64_t o0 = gb[d];
-                for (uint32_t i = lane; i < n; i += 64u)
-                    if (o0 + i < out_cap) out[o0 + i] = stage[s0 + i];
+                const uint32_t n_ok = o0 >= out_cap ? 0u : (uint32_t)min((uint64_t)n, out_cap - o0);
+                for (uint32_t i = lane; i < 3u * n_ok; i += 64u) out64[o0 * 3u + i] = stage64[(uint64_t)s0 * 3u + i];
             }
             __syncthreads();                                         // stage / cnt / sbase / gb are rewritten by the next tile
         }
