@@ -81,20 +81,30 @@ __global__ __launch_bounds__(kHThreads) void hit_hist_kernel(const kg_hit *__res
         if (h_lds[g]) atomicAdd(&ghist[g], h_lds[g]);
 }
 
-// single workgroup of 1024: gbase[0 .. n_groups] = exclusive scan of ghist (gbase[n_groups] = the chunk's hits);
-// cur1[d] = start of first-level bucket d, cur2[g] = gbase[g]: the cursors the two partition passes draw from
-__global__ __launch_bounds__(1024) void group_scan_kernel(const uint32_t *__restrict__ ghist, uint32_t n_groups, uint32_t *__restrict__ gbase,
-                                                          uint32_t *__restrict__ cur1, uint32_t *__restrict__ cur2, uint64_t *total_out)
+// single workgroup: gbase[0 .. n_groups] = exclusive scan of ghist (gbase[n_groups] = the chunk's hits);
+// cur1[d] = start of first-level bucket d, cur2[g] = gbase[g]: the cursors the two partition passes draw from;
+// tile_start[d] = tiles of kHTile records in the first-level buckets before d (the second pass's work items), d = 0 .. kHDigits.
+// Four waves only: a 16-wave workgroup finds no CU with 16 free wave slots while a tag pass (16 per CU) and the ordering
+// kernels of another chunk are resident, and waited for the end of the tag pass (2.1 ms, profiles/r03_ordering.md).
+constexpr uint32_t kGsThreads = 256, kGsPer = 4;
+__global__ __launch_bounds__(kGsThreads) void group_scan_kernel(const uint32_t *__restrict__ ghist, uint32_t n_groups, uint32_t *__restrict__ gbase,
+                                                                uint32_t *__restrict__ cur1, uint32_t *__restrict__ cur2, uint64_t *total_out,
+                                                                uint32_t *__restrict__ tile_start)
 {
-    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t wsum[kGsThreads / 64];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t b = 0; b < n_groups; b += 1024) {
-        const uint32_t i = b + threadIdx.x;
-        const uint32_t x = i < n_groups ? ghist[i] : 0u;
-        uint32_t incl = x;
+    for (uint32_t b = 0; b < n_groups; b += kGsThreads * kGsPer) {
+        const uint32_t i0 = b + threadIdx.x * kGsPer;              // kGsPer consecutive groups per thread
+        uint32_t x[kGsPer], mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kGsPer; k++) {
+            x[k] = i0 + k < n_groups ? ghist[i0 + k] : 0u;
+            mine += x[k];
+        }
+        uint32_t incl = mine;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t y = __shfl_up(incl, off);
             if (lane >= off) incl += y;
@@ -102,26 +112,47 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const uint32_t *__rest
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
         uint32_t wbase = 0, all = 0;
-        for (int w = 0; w < 16; w++) {
-            const uint32_t s = wsum[w];
-            if (w < wave) wbase += s;
-            all += s;
+        for (int w = 0; w < (int)(kGsThreads / 64); w++) {
+            const uint32_t sw = wsum[w];
+            if (w < wave) wbase += sw;
+            all += sw;
         }
         const uint32_t c = carry;
-        if (i < n_groups) {
-            const uint32_t e = c + wbase + incl - x;
-            gbase[i] = e;
-            cur2[i] = e;
-            if ((i & (kHDigits - 1)) == 0) cur1[i / kHDigits] = e;
+        uint32_t e = c + wbase + incl - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < kGsPer; k++) {
+            const uint32_t i = i0 + k;
+            if (i < n_groups) {
+                gbase[i] = e;
+                cur2[i] = e;
+                if ((i & (kHDigits - 1)) == 0) cur1[i / kHDigits] = e;
+            }
+            e += x[k];
         }
         __syncthreads();
         if (threadIdx.x == 0) carry = c + all;
         __syncthreads();
     }
+    const uint32_t n_d1 = (n_groups + kHDigits - 1) / kHDigits;
     if (threadIdx.x == 0) {
         gbase[n_groups] = carry;
-        cur1[(n_groups + kHDigits - 1) / kHDigits] = carry;      // end sentinel of the last first-level bucket
+        cur1[n_d1] = carry;                                      // end sentinel of the last first-level bucket
         *total_out = carry;
+    }
+    __syncthreads();                                             // cur1[0 .. n_d1] as written above, by this workgroup
+    const uint32_t d = threadIdx.x;                              // (two waves' worth of buckets; the others carry zeros)
+    const uint32_t t = d < n_d1 ? (cur1[d + 1] - cur1[d] + kHTile - 1) / kHTile : 0u;
+    uint32_t incl = t;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    if (d == 63) wsum[0] = incl;
+    __syncthreads();
+    if (d < kHDigits) {
+        const uint32_t before = d >= 64 ? wsum[0] : 0u;
+        tile_start[d] = before + incl - t;
+        if (d == kHDigits - 1) tile_start[kHDigits] = before + incl;
     }
 }
 
@@ -132,7 +163,8 @@ template <bool FIRST>
 __global__ __launch_bounds__(kHThreads) void hit_partition_kernel(const kg_hit *__restrict__ in, const uint32_t *__restrict__ chunk_used,
                                                                   const unsigned long long *__restrict__ cursor, uint64_t in_cap,
                                                                   const uint32_t *__restrict__ gbase, uint32_t n_groups, uint32_t g0, uint32_t gs,
-                                                                  uint32_t *cur, kg_hit *__restrict__ out, uint64_t out_cap)
+                                                                  uint32_t *cur, kg_hit *__restrict__ out, uint64_t out_cap,
+                                                                  const uint32_t *__restrict__ tile_start)
 {
     __shared__ __attribute__((aligned(16))) kg_hit stage[kHTile];
     __shared__ uint32_t hist[kHDigits], cnt[kHDigits], sbase[kHDigits], gb[kHDigits];
@@ -145,17 +177,12 @@ __global__ __launch_bounds__(kHThreads) void hit_partition_kernel(const kg_hit *
         n_res = (uint32_t)((cc < in_cap ? cc : in_cap) / kUChunk);
     }
     // work items: FIRST: tiles of kHTile / kUChunk reservation chunks; else the tiles of all first-level buckets, numbered
-    // through (tstart[d1] = tiles of the buckets before d1), so that every workgroup has work whatever the bucket sizes
+    // through (tstart[d1] = tiles of the buckets before d1, from group_scan_kernel), so that every workgroup has work whatever
+    // the bucket sizes.  (One thread summing the buckets here -- every workgroup reading the same 2 x n_d1 words one after the
+    // other -- cost 0.4 ms per launch: 768 requests for one line queue up at its L2 channel.)
     __shared__ uint32_t tstart[kHDigits + 1];
     if (!FIRST) {
-        if (tid == 0) {
-            uint32_t acc = 0;
-            for (uint32_t d = 0; d < n_d1; d++) {
-                tstart[d] = acc;
-                acc += (gbase[min((d + 1) * kHDigits, n_groups)] - gbase[d * kHDigits] + kHTile - 1) / kHTile;
-            }
-            for (uint32_t d = n_d1; d <= kHDigits; d++) tstart[d] = acc;
-        }
+        if (tid <= kHDigits) tstart[tid] = tile_start[tid];
         __syncthreads();
     }
     const uint32_t n_items = FIRST ? (n_res + kHTile / kUChunk - 1) / (kHTile / kUChunk) : tstart[kHDigits];

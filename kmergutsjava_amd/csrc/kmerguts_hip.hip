@@ -177,7 +177,8 @@ struct kg_table {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // partitioned scan: tag pass of chunk c while chunk c+1 is scattered (stream)
     hipStream_t stream3 = nullptr;      // ... and while chunk c-1 is verified and placed
-    hipEvent_t pev[32] = {};            // [2c] chunk c scattered, [2c+1] chunk c tag-probed (c < 8); [16],[17],[18] fork / joins;
+    hipStream_t ostream[4] = {};        // ordering streams (KG_ORDER_STREAMS), lowest priority: queues of their own
+    hipEvent_t pev[48] = {};            // [2c] chunk c scattered, [2c+1] chunk c tag-probed (c < 8); [16],[17],[18] fork / joins;
                                         // [20+c] chunk c verified
     bool own_entries = false;
     uint8_t *d_entries = nullptr;
@@ -562,6 +563,7 @@ void kg_table_close(kg_table *t)
         if (e) (void)hipEventDestroy(e);
     if (t->stream2) { (void)hipStreamSynchronize(t->stream2); (void)hipStreamDestroy(t->stream2); }
     if (t->stream3) { (void)hipStreamSynchronize(t->stream3); (void)hipStreamDestroy(t->stream3); }
+    for (auto &os : t->ostream) if (os) { (void)hipStreamSynchronize(os); (void)hipStreamDestroy(os); }
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
 }
@@ -608,6 +610,7 @@ struct Scratch {
         (void)hipStreamSynchronize(t->stream);      // blocks go back to the cache only when both streams are idle
         if (t->stream2) (void)hipStreamSynchronize(t->stream2);
         if (t->stream3) (void)hipStreamSynchronize(t->stream3);
+        for (auto &os : t->ostream) if (os) (void)hipStreamSynchronize(os);
         for (void *p : ptrs) dfree(t, p);
     }
     void adopt(void *p) { ptrs.push_back(p); }
@@ -914,7 +917,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         while (gshift < 12 && ((max_chunk * PER) >> gshift) + 2 > 8192) gshift++;
         const uint32_t groups_stride = (uint32_t)(((max_chunk * PER) >> gshift) + 2);      // a chunk's rows start anywhere inside a group
         if (groups_stride > kg::kMaxGroups) return fail(KG_ERR_LIMIT, "a chunk of the batch holds more than 2^26 window rows");
-        uint32_t *d_ghist = nullptr, *d_gbase = nullptr, *d_gcur1 = nullptr, *d_gcur2 = nullptr;
+        uint32_t *d_ghist = nullptr, *d_gbase = nullptr, *d_gcur1 = nullptr, *d_gcur2 = nullptr, *d_gtile = nullptr;
         kg_hit *d_sortA = nullptr, *d_sortB = nullptr;
         if ((rc = sc.get(&d_ent, (size_t)(n_regions_total * cap * n_chunks_p)))) return rc;
         if ((rc = sc.get(&d_fill, (size_t)n_regions_total * n_chunks_p))) return rc;
@@ -930,6 +933,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if ((rc = sc.get(&d_gbase, (size_t)(groups_stride + 1) * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_gcur1, (size_t)(kg::kHDigits + 1) * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_gcur2, (size_t)groups_stride * n_chunks_p))) return rc;
+        if ((rc = sc.get(&d_gtile, (size_t)(kg::kHDigits + 1) * n_chunks_p))) return rc;
         if (groups_stride * 4u > t->hist_lds) {
             HIP_TRY(hipFuncSetAttribute((const void *)kg::hit_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(groups_stride * 4u)));
             t->hist_lds = groups_stride * 4u;
@@ -1121,11 +1125,23 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             }
 #undef KG_PROBE_ARGS
             seq_uploaded = true;
-            // Ordered placement (kg_order.hpp), chunk by chunk on the scatter stream, i.e. behind the LAST scatter pass and
-            // beside the tag passes that are still running: its partition workgroups hold 51 KB of LDS and eight wave slots
-            // each, and started beside a scatter pass (105 KB and 16 wave slots of every CU) the two starve each other --
-            // chunk 0's two partition passes took 2.2 + 4.3 ms instead of 0.15 + 0.55 and the scatter pass beside them 7.8 ms
-            // instead of 2 (profiles/r03_ordering.md).  (A fourth stream shares a hardware queue with the third.)
+            // Ordered placement (kg_order.hpp), chunk by chunk, behind the LAST scatter pass and beside the tag passes that are
+            // still running: its partition workgroups hold 51 KB of LDS and eight wave slots each, and started beside a scatter
+            // pass (105 KB and 16 wave slots of every CU) the two starve each other -- chunk 0's two partition passes took
+            // 2.2 + 4.3 ms instead of 0.15 + 0.55 and the scatter pass beside them 7.8 ms instead of 2 (profiles/r03_ordering.md).
+            // Beside a tag pass the ordering kernels crawl (a partition pass 1.7-3.9 ms instead of 0.13: every memory access
+            // queues behind the tag pass's line gathers) while the tag pass hardly notices them.  KG_ORDER_STREAMS=n (1..4; not
+            // the default) gives the chunks' orderings n streams of their own, of the LOWEST priority because that gives them
+            // hardware queues of their own (a fourth stream of normal priority shares a queue with the third): the orderings
+            // of chunks 0-2 then all crawl beside the last tag passes, single scans 20.1-20.25 ms against 20.4, but twenty
+            // scans back to back (bench.py) 21.45 against 21.23 ms per step (profiles/r03_experiments.md).
+            const uint32_t n_os = n_chunks_p < 2 ? 0u : std::min(env_u32("KG_ORDER_STREAMS", 0u), 4u);
+            for (uint32_t k = 0; k < n_os; k++)
+                if (!t->ostream[k]) {
+                    int pr_least = 0, pr_greatest = 0;
+                    HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+                    HIP_TRY(hipStreamCreateWithPriority(&t->ostream[k], hipStreamNonBlocking, pr_least));
+                }
             for (uint32_t c = 0; c < n_chunks_p; c++) {
                 const uint32_t lo = (uint32_t)clo[c], nb = (uint32_t)(clo[c + 1] - clo[c]);
                 kg_hit *ulist_c = d_ulist + (uint64_t)c * ucap;
@@ -1133,6 +1149,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 unsigned long long *ucur_c = (unsigned long long *)(d_pc + c);
                 uint64_t *base_c = d_pc + 16 + c, *ctot_c = d_pc + 32 + c;
                 hipStream_t s3 = t->stream;
+                if (n_os) {
+                    s3 = t->ostream[c % n_os];
+                    HIP_TRY(hipStreamWaitEvent(s3, t->ev[5], 0));          // behind the last scatter pass
+                }
                 HIP_TRY(hipStreamWaitEvent(s3, t->pev[20 + c], 0));
                 // group histogram -> group starts -> two partition passes by key range -> ranking inside each group of rows
                 {
@@ -1140,18 +1160,21 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                     const uint32_t g0 = (uint32_t)(row_lo >> gshift);
                     const uint32_t n_groups = nb ? (uint32_t)(((row_hi - 1) >> gshift) - g0 + 1) : 1u;
                     uint32_t *ghist_c = d_ghist + (size_t)c * groups_stride, *gbase_c = d_gbase + (size_t)c * (groups_stride + 1);
-                    uint32_t *gcur1_c = d_gcur1 + (size_t)c * (kg::kHDigits + 1), *gcur2_c = d_gcur2 + (size_t)c * groups_stride;
+                    uint32_t *gcur1_c = d_gcur1 + (size_t)c * (kg::kHDigits + 1), *gcur2_c = d_gcur2 + (size_t)c * groups_stride,
+                             *gtile_c = d_gtile + (size_t)c * (kg::kHDigits + 1);
                     kg_hit *sortA_c = d_sortA + (uint64_t)c * ucap, *sortB_c = d_sortB + (uint64_t)c * ucap;
                     const uint32_t ogrid = env_u32("KG_ORDER_GRID", 256u * 3u);
                     hipLaunchKernelGGL(kg::hit_hist_kernel, dim3(ogrid), dim3(kg::kHThreads), (size_t)n_groups * 4, s3, ulist_c, cused_c, ucur_c, ucap,
                                        g0, 6u + gshift, n_groups, ghist_c);
-                    hipLaunchKernelGGL(kg::group_scan_kernel, dim3(1), dim3(1024), 0, s3, ghist_c, n_groups, gbase_c, gcur1_c, gcur2_c, ctot_c);
+                    hipLaunchKernelGGL(kg::group_scan_kernel, dim3(1), dim3(kg::kGsThreads), 0, s3, ghist_c, n_groups, gbase_c, gcur1_c, gcur2_c, ctot_c, gtile_c);
+                    if (n_os && c) HIP_TRY(hipStreamWaitEvent(s3, t->pev[32 + c - 1], 0));      // base of chunk c = base + total of c - 1
                     hipLaunchKernelGGL(kg::chunk_base_kernel, dim3(1), dim3(1), 0, s3, ctot_c, base_c,
                                        c + 1 == n_chunks_p ? d_totals : (uint64_t *)nullptr);
+                    if (n_os) HIP_TRY(hipEventRecord(t->pev[32 + c], s3));
                     hipLaunchKernelGGL((kg::hit_partition_kernel<true>), dim3(ogrid), dim3(kg::kHThreads), 0, s3, ulist_c, cused_c, ucur_c, ucap,
-                                       gbase_c, n_groups, g0, 6u + gshift, gcur1_c, sortA_c, ucap);
+                                       gbase_c, n_groups, g0, 6u + gshift, gcur1_c, sortA_c, ucap, gtile_c);
                     hipLaunchKernelGGL((kg::hit_partition_kernel<false>), dim3(ogrid), dim3(kg::kHThreads), 0, s3, sortA_c, cused_c, ucur_c, ucap,
-                                       gbase_c, n_groups, g0, 6u + gshift, gcur2_c, sortB_c, ucap);
+                                       gbase_c, n_groups, g0, 6u + gshift, gcur2_c, sortB_c, ucap, gtile_c);
                     hipLaunchKernelGGL((kg::group_place_kernel<AA>), dim3(std::min(n_groups, 256u * 8u)), dim3(kg::kHThreads), (size_t)12 << gshift, s3,
                                        sortB_c, gbase_c, n_groups, g0, gshift, (uint32_t)row_lo, (uint32_t)row_hi, d_geo, base_c, res->d_hits,
                                        hits_cap, d_offs);
@@ -1159,6 +1182,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 HIP_TRY(hipGetLastError());
             }
 
+            for (uint32_t k = 0; k < n_os; k++) {
+                HIP_TRY(hipEventRecord(t->pev[40 + k], t->ostream[k]));
+                HIP_TRY(hipStreamWaitEvent(t->stream, t->pev[40 + k], 0));
+            }
             HIP_TRY(hipEventRecord(t->pev[17], t->stream2));              // join
             HIP_TRY(hipStreamWaitEvent(t->stream, t->pev[17], 0));
             HIP_TRY(hipEventRecord(t->pev[18], t->stream3));
