@@ -40,6 +40,27 @@ constexpr int kMaxBuckets = 1024;
 #ifndef KG_PROBE_N
 #define KG_PROBE_N 4
 #endif
+// Register budgets.  The scatter pass of chunk c + 1 and the tag pass of chunk c share the CUs, and what decides how many tag
+// waves run beside a scatter workgroup (16 waves, 4 per SIMD) is the SIMD's 512 VGPRs: 4 x 104 (99 rounded to the
+// allocation granule of 8) left room for ONE tag wave of 72 (66) per SIMD -- the tag pass ran beside a scatter pass with a
+// quarter of its waves.  amdgpu_waves_per_eu(5) holds the scatter kernel to 96 VGPRs (no spill) and the tag kernel's slot
+// arithmetic in 32 bits brings it to 61: 4 x 96 + 2 x 64 = 512, two tag waves per SIMD.
+#ifndef KG_SCATTER_WPE
+#define KG_SCATTER_WPE 5
+#endif
+#ifndef KG_TAG_WPE
+#define KG_TAG_WPE 8
+#endif
+#if KG_SCATTER_WPE
+#define KG_SCATTER_REGS __attribute__((amdgpu_waves_per_eu(KG_SCATTER_WPE)))
+#else
+#define KG_SCATTER_REGS
+#endif
+#if KG_TAG_WPE
+#define KG_TAG_REGS __attribute__((amdgpu_waves_per_eu(KG_TAG_WPE)))
+#else
+#define KG_TAG_REGS
+#endif
 constexpr int kProbeN = KG_PROBE_N;                  // queries per lane per iteration of the bucket probe
 constexpr uint32_t kUChunk = 512;           // records per reservation of the unordered hit list
 
@@ -53,7 +74,10 @@ __device__ __forceinline__ uint32_t window_key(const BlockDesc &bd, uint32_t it,
     const uint32_t ol = (!AA && r >= 3) ? 63u - (uint32_t)lane : (uint32_t)lane;
     return (row_index<AA>(bd, it, r) << 6) | ol;
 }
-constexpr int kScatterWaves = 16;           // waves per scatter workgroup (one workgroup per CU: its LDS holds the buffers)
+#ifndef KG_SCATTER_WAVES
+#define KG_SCATTER_WAVES 16
+#endif
+constexpr int kScatterWaves = KG_SCATTER_WAVES;           // waves per scatter workgroup (one workgroup per CU: its LDS holds the buffers)
 constexpr uint32_t kGroup = 16;             // entries per write-combining buffer = one 128-byte line
 
 template <bool AA>
@@ -75,7 +99,7 @@ inline size_t scatter_lds_bytes(uint32_t n_buckets)
 // region goes to the overflow list (skewed inputs), which is probed separately.  Layout of the entry array:
 // region (bucket b, workgroup w) = [ (b * n_wg + w) * cap , + fill[b * n_wg + w] ).
 template <bool AA>
-__global__ __launch_bounds__(kWave *kScatterWaves) void part_scatter_kernel(
+__global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_scatter_kernel(
     const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t block_lo, uint32_t n_blocks /* of this launch */,
     uint64_t limit, uint32_t num_sigs /* 64 <= num_sigs < 2^31 */, uint32_t m35, uint32_t shift, uint32_t n_buckets, uint32_t cap,
     uint64_t *__restrict__ ent, uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap, uint32_t *__restrict__ ovf_bucket,
@@ -560,7 +584,7 @@ __device__ __forceinline__ void chunk_finish(const UListState &u, uint32_t *__re
 // workgroup one more round trip per bucket -- the draw that finds the bucket exhausted: 0.15-0.25 ms of a 100-125 Mbp
 // batch, nothing at 1 Gbp; profiles/r02_pipeline.md section 5.)
 template <bool COUNTERS>
-__global__ __launch_bounds__(256) void bucket_tag_kernel(
+__global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
     const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, const uint64_t *__restrict__ ent,
     const uint32_t *__restrict__ fill, uint32_t n_regions, uint32_t cap, uint32_t n_buckets, uint32_t shift,
     uint32_t grab /* entry slots per hand-out, multiple of 256 * kProbeN */,
@@ -569,6 +593,7 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
     unsigned long long *ctr)
 {
     constexpr int N = kProbeN;
+    const uint32_t lim32 = (uint32_t)limit;
     __shared__ uint32_t s_region;
     const int lane = threadIdx.x & 63;
     unsigned long long ctr_slots = 0;
@@ -598,7 +623,7 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
         const uint64_t *src = ent + ((uint64_t)b * n_regions + w) * cap;
         for (uint32_t c0 = g0; c0 < n && c0 < g0 + kGrab; c0 += 256u * N) {
             const uint32_t bound = n;
-            uint64_t home[N], cur[N];
+            uint32_t home[N], cur[N];               // slots: below 2^31 on this path (the scatter pass's split_fast needs numSigs < 2^31)
             uint32_t id[N], quo[N], fp[N], skip[N];
             bool valid[N];
             Tags16 tg[N];
@@ -621,10 +646,10 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                 valid[k] = e != kEntInvalid;
                 const uint32_t low = (uint32_t)e;
                 id[k] = (uint32_t)(e >> 32);
-                home[k] = ((uint64_t)b << shift) | (low & ((1u << shift) - 1u));
+                home[k] = (b << shift) | (low & ((1u << shift) - 1u));
                 quo[k] = low >> shift;
                 fp[k] = tag_qs(quo[k], home[k]);
-                cur[k] = probe_window(home[k], &skip[k]);
+                cur[k] = (uint32_t)probe_window(home[k], &skip[k]);
                 if (valid[k]) tg[k] = load_tags(tags + cur[k]);
             }
             // a window that holds neither an empty slot nor the fingerprint (2 % of the probes: straddling windows,
@@ -636,12 +661,12 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                 if (valid[k]) {
                     bool emp;
                     const int i = first_stop(tg[k], fp[k], &emp, skip[k]);
-                    cur[k] += (uint64_t)i;
+                    cur[k] += (uint32_t)i;
                     if (i == 16) { candm |= 1u << k; walkm |= 1u << k; }
                     else if (!emp) candm |= 1u << k;
                     else {
-                        if (cur[k] >= limit) ran_off = true;   // the "empty slot" is the padding behind the last record
-                        if (COUNTERS) ctr_slots += (cur[k] < limit ? cur[k] + 1 : limit) - home[k];
+                        if (cur[k] >= lim32) ran_off = true;   // the "empty slot" is the padding behind the last record
+                        if (COUNTERS) ctr_slots += (cur[k] < lim32 ? cur[k] + 1u : lim32) - home[k];
                     }
                 }
             }
@@ -665,8 +690,8 @@ __global__ __launch_bounds__(256) void bucket_tag_kernel(
                     for (int k = 0; k < N; k++) {
                         if ((candm >> k) & 1u) {
                             CandRec c;
-                            c.home = (uint32_t)home[k]; c.quo = quo[k];
-                            c.id = id[k]; c.walked = (uint32_t)(cur[k] - home[k]) | (((walkm >> k) & 1u) ? kWalkOn : 0u);
+                            c.home = home[k]; c.quo = quo[k];
+                            c.id = id[k]; c.walked = (cur[k] - home[k]) | (((walkm >> k) & 1u) ? kWalkOn : 0u);
                             cand[at + rank[k]] = c;
                         }
                         at += cnt[k];

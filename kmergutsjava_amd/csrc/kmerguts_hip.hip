@@ -843,7 +843,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                   : kg::scatter_lds_bytes<false>((uint32_t)((t->limit + (1ull << shift) - 1) >> shift)) > 160u * 1024)
             shift++;
         // the scatter pass splits k-mers with kg::split_fast: 64 <= numSigs < 2^31
-        const bool fits = shift < 32 && qmax < (1ull << (32 - shift)) && nblocks <= (1ull << 23) && t->m35 != 0;
+        // (and the tag / verify passes keep slots in 32 bits: a table FILE may be longer than numSigs, KGJ:964-999)
+        const bool fits = shift < 32 && qmax < (1ull << (32 - shift)) && nblocks <= (1ull << 23) && t->m35 != 0 &&
+                          t->limit < (1ull << 32) - 64;
         // Measured against the 33.6 GB table (profiles/r01_partition_path.md), whole scan incl. ordering, direct vs
         // partitioned: 1 Gbp 35.0 / 21.4 ms, 600 Mbp 21.8 / 13.6, 400 Mbp 14.6 / 9.4, 200 Mbp 7.0 / 5.4, 100 Mbp 3.6 / 3.4 (one chunk).
         // Small inputs and L2/MALL-sized tables stay on the direct kernel.
@@ -984,10 +986,12 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             t->scatter_lds[AA ? 1 : 0] = lds;
         }
-        // 4 tag workgroups (16 waves) per CU: leaves the 16 wave slots a scatter workgroup of the next chunk needs, so the
-        // two passes really share the CUs; with 8 (all 32 slots) the scatter pass queues behind the persistent tag
-        // workgroups (profiles/r02_pipeline.md: 20.8 -> 20.4 ms per Gbp)
-        const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 4u) & ~7u;
+        // Tag workgroups per CU.  How many of them run beside a scatter workgroup of the next chunk is decided by the SIMDs'
+        // VGPRs (kg_partition.hpp, "Register budgets": two per CU since round 3, one before), the rest wait for the scatter
+        // workgroup to leave; the hand-out is by ticket, so the count only decides how fast freed registers are taken up.
+        // Round 2 (one tag wave per SIMD beside the scatter pass): 4 per CU 20.4 ms, 8 per CU 20.8 (profiles/r02_pipeline.md);
+        // round 3 (two): 4 per CU 19.78 ms, 8 per CU 19.56, bench.py 20.5 -> 20.25 ms per step (profiles/r03_experiments.md).
+        const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 8u) & ~7u;
         const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
         // The two kernels that usually find nothing to do (no low-complexity block set aside, no overflow group) sit on the
         // stage's critical chain -- in front of every tag pass and behind every verify pass -- and beside the other passes a
