@@ -242,12 +242,18 @@ __device__ __forceinline__ uint32_t walk_unit(const kg_hit *__restrict__ hits, c
     // "no such chunk": a base no record index comes within 64 of (kg_scan takes < 2^32 - 256 hit records)
     pv.base = ppv.base = 0xFFFFFF00u; pv.mask = ppv.mask = 0; pv.fI = ppv.fI = pv.pos = ppv.pos = 0; pv.wt = ppv.wt = 0.f;
 
-    // the next chunk's fields are requested before the current chunk is worked on: a long unit is a chain of chunks
-    int32_t n_pos = 0, n_fI = 0, n_avg = 0;
-    float n_wt = 0.f;
+    // the fields of the next TWO chunks are requested before the current chunk is worked on: a long unit is a chain of
+    // chunks, each a dependent step of the machine, and one chunk of look-ahead left every step waiting for most of a
+    // memory round trip
+    int32_t n_pos = 0, n_fI = 0, n_avg = 0, m_pos = 0, m_fI = 0, m_avg = 0;
+    float n_wt = 0.f, m_wt = 0.f;
     if (begin + (uint32_t)lane < end) {
         const kg_hit &h0 = hits[begin + lane];
         n_pos = h0.from0InProt; n_fI = h0.fI; n_avg = h0.avgOffFromEnd; n_wt = h0.functionWt;
+    }
+    if (begin + 64u + (uint32_t)lane < end) {
+        const kg_hit &h1 = hits[begin + 64u + lane];
+        m_pos = h1.from0InProt; m_fI = h1.fI; m_avg = h1.avgOffFromEnd; m_wt = h1.functionWt;
     }
     for (uint32_t base = begin; base < end; base += 64) {
         int n = (int)min(64u, end - base);
@@ -266,10 +272,11 @@ __device__ __forceinline__ uint32_t walk_unit(const kg_hit *__restrict__ hits, c
         int32_t pos = n_pos, fI = n_fI, avg = n_avg;
         float wt = n_wt;
         if (lane >= n) { pos = 0; fI = 0; avg = 0; wt = 0.f; }      // (a chunk cut short by the next piece)
-        n_pos = 0; n_fI = 0; n_avg = 0; n_wt = 0.f;
-        if (base + 64u + (uint32_t)lane < end) {
-            const kg_hit &h1 = hits[base + 64u + lane];
-            n_pos = h1.from0InProt; n_fI = h1.fI; n_avg = h1.avgOffFromEnd; n_wt = h1.functionWt;
+        n_pos = m_pos; n_fI = m_fI; n_avg = m_avg; n_wt = m_wt;
+        m_pos = 0; m_fI = 0; m_avg = 0; m_wt = 0.f;
+        if (base + 128u + (uint32_t)lane < end) {
+            const kg_hit &h2 = hits[base + 128u + lane];
+            m_pos = h2.from0InProt; m_fI = h2.fI; m_avg = h2.avgOffFromEnd; m_wt = h2.functionWt;
         }
         uint64_t accmask;
         uint64_t votes = 0;                          // records of this chunk whose vote counted towards a CALL
