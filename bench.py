@@ -299,7 +299,8 @@ def main():
                                         "DESIGN.md section 6") if partitioned else
                                        "direct probing: every 16-byte probe moves a 128-byte line from HBM",
                          "kernel": ("scan stage = kg::part_scatter_kernel || kg::bucket_tag_kernel || kg::verify_kernel + "
-                                    "kg::place_unordered_kernel (chunks of whole contigs on three streams)" if partitioned else "kg::scan_kernel<false,false,3>"),
+                                    "ordered placement (kg::hit_partition_kernel x 2, kg::group_place_kernel): chunks of whole "
+                                    "contigs on three streams" if partitioned else "kg::scan_kernel<false,false,3>"),
                          "kernel_ms": ms_scan,
                          "passes_ms": ({k: float(np.mean(v)) for k, v in pass_ms.items()} if partitioned else None),
                          "strategy": "partitioned" if partitioned else "direct",
