@@ -595,6 +595,9 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
     constexpr int N = kProbeN;
     const uint32_t lim32 = (uint32_t)limit;
     __shared__ uint32_t s_region;
+    __shared__ __attribute__((aligned(16))) CandRec s_stage[4][128];      // per wave: < 64 records waiting + <= 64 new ones
+    CandRec *stage = s_stage[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+    uint32_t sfill = 0;                                                    // (wave-uniform)
     const int lane = threadIdx.x & 63;
     unsigned long long ctr_slots = 0;
     bool ran_off = false;
@@ -623,10 +626,14 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
         const uint64_t *src = ent + ((uint64_t)b * n_regions + w) * cap;
         for (uint32_t c0 = g0; c0 < n && c0 < g0 + kGrab; c0 += 256u * N) {
             const uint32_t bound = n;
-            uint32_t home[N], cur[N];               // slots: below 2^31 on this path (the scatter pass's split_fast needs numSigs < 2^31)
-            uint32_t id[N], quo[N], fp[N], skip[N];
-            bool valid[N];
+            // Per entry the lane keeps the entry's two words, its fingerprint and (after the compare) the slots walked; the
+            // home slot and the quotient are recomputed from the low word where they are needed (two instructions) -- the
+            // kernel has to stay within 64 VGPRs (kg_partition.hpp, "Register budgets").  Slots are below 2^31 on this
+            // path (the scatter pass's split_fast needs numSigs < 2^31).
+            uint32_t low[N], id[N], fp[N], skip[N], walked[N];
+            uint32_t vmask = 0;
             Tags16 tg[N];
+            const uint32_t smask = (1u << shift) - 1u, bbase = b << shift;
             // all entry loads first, then all tag loads: N independent L2 requests in flight per lane (loads
             // complete in order, so interleaving entry and tag loads serialises them)
             uint64_t ev[N];
@@ -643,14 +650,13 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 const uint64_t e = c0 + (uint32_t)k * 256u + threadIdx.x < n ? ev[k] : kEntInvalid;
-                valid[k] = e != kEntInvalid;
-                const uint32_t low = (uint32_t)e;
+                if (e != kEntInvalid) vmask |= 1u << k;
+                low[k] = (uint32_t)e;
                 id[k] = (uint32_t)(e >> 32);
-                home[k] = (b << shift) | (low & ((1u << shift) - 1u));
-                quo[k] = low >> shift;
-                fp[k] = tag_qs(quo[k], home[k]);
-                cur[k] = (uint32_t)probe_window(home[k], &skip[k]);
-                if (valid[k]) tg[k] = load_tags(tags + cur[k]);
+                const uint32_t home = bbase | (low[k] & smask);
+                fp[k] = tag_qs(low[k] >> shift, home);
+                const uint32_t cur = (uint32_t)probe_window(home, &skip[k]);     // home - skip (skip != 0: the window straddles a line)
+                if ((vmask >> k) & 1u) tg[k] = load_tags(tags + cur);
             }
             // a window that holds neither an empty slot nor the fingerprint (2 % of the probes: straddling windows,
             // long clusters) is not walked here: it goes to the candidate list with kWalkOn set and the verify pass
@@ -658,15 +664,17 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
             uint32_t candm = 0, walkm = 0;
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                if (valid[k]) {
+                walked[k] = 0;
+                if ((vmask >> k) & 1u) {
                     bool emp;
                     const int i = first_stop(tg[k], fp[k], &emp, skip[k]);
-                    cur[k] += (uint32_t)i;
+                    walked[k] = (uint32_t)i - skip[k];                          // slots from the home slot
                     if (i == 16) { candm |= 1u << k; walkm |= 1u << k; }
                     else if (!emp) candm |= 1u << k;
                     else {
-                        if (cur[k] >= lim32) ran_off = true;   // the "empty slot" is the padding behind the last record
-                        if (COUNTERS) ctr_slots += (cur[k] < lim32 ? cur[k] + 1u : lim32) - home[k];
+                        const uint32_t home = bbase | (low[k] & smask), at = home + walked[k];
+                        if (at >= lim32) ran_off = true;       // the "empty slot" is the padding behind the last record
+                        if (COUNTERS) ctr_slots += (at < lim32 ? at + 1u : lim32) - home;
                     }
                 }
             }
@@ -674,31 +682,44 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
             //  costs the verify pass a random tag line -- was built and measured in round 3: verify 1.84 -> 1.55 ms alone, but
             //  this kernel, the stage's critical chain, 3.9 -> 4.1 ms per chunk beside the scatter pass: stage 20.3 -> 20.8 ms.
             //  profiles/r03_experiments.md.)
-            // candidates -> list
-            uint32_t cnt[N], rank[N], total = 0;
+            // candidates -> the wave's staging buffer in LDS -> the list, 64 records (1 KB, eight whole lines) per store
+            // instruction.  (Stored straight from the registers -- four store instructions per batch with ~3 active lanes
+            // each -- the candidate output was 0.8 ms of the pass alone, for 1 GB of records.)
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 const unsigned long long m = __ballot((candm >> k) & 1u);
-                cnt[k] = (uint32_t)__popcll(m);
-                rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                total += cnt[k];
-            }
-            if (total) {
-                unsigned long long at = chunk_reserve(u, total, cand_used, cand_cursor, cand_cap, lane);
-                if (at != ~0ull) {
-#pragma unroll
-                    for (int k = 0; k < N; k++) {
-                        if ((candm >> k) & 1u) {
-                            CandRec c;
-                            c.home = home[k]; c.quo = quo[k];
-                            c.id = id[k]; c.walked = (cur[k] - home[k]) | (((walkm >> k) & 1u) ? kWalkOn : 0u);
-                            cand[at + rank[k]] = c;
-                        }
-                        at += cnt[k];
+                if (!m) continue;                                          // (uniform)
+                if ((candm >> k) & 1u) {
+                    CandRec c;
+                    c.home = bbase | (low[k] & smask); c.quo = low[k] >> shift;
+                    c.id = id[k]; c.walked = walked[k] | (((walkm >> k) & 1u) ? kWalkOn : 0u);
+                    stage[sfill + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c;
+                }
+                sfill += (uint32_t)__popcll(m);                            // < 64 + 64
+                if (sfill >= 64u) {
+                    // (one wave's LDS operations execute in program order: the fences only pin the compiler's order)
+                    wave_sync();
+                    const unsigned long long at = chunk_reserve(u, 64u, cand_used, cand_cursor, cand_cap, lane);
+                    {
+                        const ulonglong2 out = *reinterpret_cast<const ulonglong2 *>(stage + lane);
+                        if (at != ~0ull) *reinterpret_cast<ulonglong2 *>(cand + at + (uint32_t)lane) = out;
                     }
+                    sfill -= 64u;
+                    wave_sync();
+                    if ((uint32_t)lane < sfill) {                          // the remainder moves down
+                        const ulonglong2 rest = *reinterpret_cast<const ulonglong2 *>(stage + 64 + lane);
+                        *reinterpret_cast<ulonglong2 *>(stage + lane) = rest;
+                    }
+                    wave_sync();
                 }
             }
         }
+    }
+    if (sfill) {                                                           // the wave's last, partial group
+        wave_sync();
+        const CandRec out = stage[(uint32_t)lane < sfill ? lane : 0];
+        const unsigned long long at = chunk_reserve(u, sfill, cand_used, cand_cursor, cand_cap, lane);
+        if (at != ~0ull && (uint32_t)lane < sfill) cand[at + (uint32_t)lane] = out;
     }
     chunk_finish(u, cand_used, cand_cap, lane);
     flush_ran_off(ran_off, ctr, lane);
