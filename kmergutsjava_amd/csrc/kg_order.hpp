@@ -265,17 +265,30 @@ __global__ __launch_bounds__(kHThreads) void hit_partition_kernel(const kg_hit *
     }
 }
 
-// One workgroup per group of 2^gshift rows.  Dynamic LDS: (8 + 4) << gshift bytes.
+// One workgroup per group of 2^gshift rows.  Dynamic LDS: (8 + 4) << gshift bytes, and with `staged` (8 + 4 + 8) << gshift
+// + kPlaceOut * 24: the rows' geometry records are brought in with one coalesced read and the group's records are put in
+// order in LDS and leave as a flat stream of 8-byte words.  (Placed straight from the registers every record cost a gather
+// lane for its row's geometry and two store lanes into the group's output range, 64 different lines per wave
+// instruction: 110 M partially used lines per Gbp in the CUs' vector memory path, which is what the stage's passes compete
+// for.)  A group with more than kPlaceOut records (dense inputs) is placed directly.
+constexpr uint32_t kPlaceOut = 1536;       // a group of 1024 rows holds ~1150 hits of the 1 Gbp contig mix
+__host__ __device__ inline size_t group_place_lds(uint32_t gshift, bool staged)
+{
+    return staged ? ((size_t)20 << gshift) + (size_t)kPlaceOut * sizeof(kg_hit) : ((size_t)12 << gshift);
+}
 template <bool AA>
 __global__ __launch_bounds__(kHThreads) void group_place_kernel(const kg_hit *__restrict__ in, const uint32_t *__restrict__ gbase, uint32_t n_groups,
                                                                 uint32_t g0, uint32_t gshift, uint32_t row_lo, uint32_t row_hi /* the chunk's rows */,
-                                                                const RowGeo *__restrict__ geo, const uint64_t *__restrict__ base,
+                                                                const RowGeo *__restrict__ geo, uint64_t n_rows_all, uint32_t staged,
+                                                                const uint64_t *__restrict__ base,
                                                                 kg_hit *__restrict__ hits, uint64_t hits_cap, uint32_t *__restrict__ offs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char p_lds[];
     const uint32_t R = 1u << gshift;
     unsigned long long *masks = reinterpret_cast<unsigned long long *>(p_lds);
     uint32_t *pre = reinterpret_cast<uint32_t *>(masks + R);
+    RowGeo *lgeo = reinterpret_cast<RowGeo *>(pre + R);                   // (staged only)
+    uint64_t *lout = reinterpret_cast<uint64_t *>(lgeo + R);              // (staged only) kPlaceOut records of three words
     __shared__ uint32_t wsum[kHThreads / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t chunk_base = *base;
@@ -283,7 +296,11 @@ __global__ __launch_bounds__(kHThreads) void group_place_kernel(const kg_hit *__
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint32_t lo = gbase[g], n = gbase[g + 1] - lo;
         const uint64_t row0 = (uint64_t)(g0 + g) << gshift;
-        for (uint32_t i = tid; i < R; i += kHThreads) masks[i] = 0ull;
+        const bool to_lds = staged && n <= kPlaceOut;
+        for (uint32_t i = tid; i < R; i += kHThreads) {
+            masks[i] = 0ull;
+            if (staged && n && row0 + i < n_rows_all) lgeo[i] = geo[row0 + i];
+        }
         __syncthreads();
         // the group's records are read once and wait in registers for their rank when there are at most kKeep per thread
         // (a group of 1024 rows holds ~1150 hits of the 1 Gbp contig mix); larger groups are read a second time
@@ -330,11 +347,18 @@ __global__ __launch_bounds__(kHThreads) void group_place_kernel(const kg_hit *__
         __syncthreads();
         auto place = [&](kg_hit h) {
             const uint32_t key = h.container, rl = (key >> 6) & (R - 1u), ol = key & 63u;
-            const RowGeo gr = geo[key >> 6];
-            const uint64_t dst = chunk_base + lo + pre[rl] + (uint32_t)__popcll(masks[rl] & ((1ull << ol) - 1ull));
+            const RowGeo gr = staged ? lgeo[rl] : geo[key >> 6];
+            const uint32_t rank = pre[rl] + (uint32_t)__popcll(masks[rl] & ((1ull << ol) - 1ull));      // inside the group
             h.container = gr.container;
             h.from0InProt = gr.pos_first + (int32_t)ol;
-            if (dst < hits_cap) hits[dst] = h;              // only out of range when a list overflowed: that scan is re-run
+            if (to_lds) {
+                uint64_t w3[3];
+                __builtin_memcpy(w3, &h, 24);
+                lout[3u * rank] = w3[0]; lout[3u * rank + 1] = w3[1]; lout[3u * rank + 2] = w3[2];
+            } else {
+                const uint64_t dst = chunk_base + lo + rank;
+                if (dst < hits_cap) hits[dst] = h;          // only out of range when a list overflowed: that scan is re-run
+            }
         };
         if (keep) {
 #pragma unroll
@@ -343,7 +367,14 @@ __global__ __launch_bounds__(kHThreads) void group_place_kernel(const kg_hit *__
         } else {
             for (uint32_t k = tid; k < n; k += kHThreads) place(in[lo + k]);
         }
-        __syncthreads();                                    // masks / pre are rewritten by the next group
+        __syncthreads();                                    // masks / pre / lgeo are rewritten by the next group; lout is complete
+        if (to_lds) {
+            const uint64_t dst0 = chunk_base + lo;
+            const uint32_t n_ok = dst0 >= hits_cap ? 0u : (uint32_t)min((uint64_t)n, hits_cap - dst0);
+            uint64_t *out64 = reinterpret_cast<uint64_t *>(hits) + dst0 * 3u;
+            for (uint32_t i = tid; i < 3u * n_ok; i += kHThreads) out64[i] = lout[i];
+            __syncthreads();                                // lout is rewritten by the next group
+        }
     }
 }
 

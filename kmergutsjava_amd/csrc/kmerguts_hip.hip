@@ -195,6 +195,7 @@ struct kg_table {
     double stage_ratio = 1.0 / 16;   // staging records per window, grown to the high-water mark
     size_t scatter_lds[2] = {0, 0};  // dynamic LDS the scatter kernel (DNA / protein) has been allowed so far
     size_t hist_lds = 48 * 1024;     // ... and the hit histogram kernel (kg_order.hpp)
+    size_t place_lds[2] = {48 * 1024, 48 * 1024};   // ... and group_place_kernel<DNA / AA>
     size_t probe2_lds[3] = {0, 0, 0};   // ... and the second-level probe kernels (tags without / with counters, home index)
     hipEvent_t ev[8] = {};
     // Pinned host words for the few counters a scan reads back (a hipMemcpyAsync to pageable memory blocks the host per
@@ -936,6 +937,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if ((rc = sc.get(&d_gcur1, (size_t)(kg::kHDigits + 1) * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_gcur2, (size_t)groups_stride * n_chunks_p))) return rc;
         if ((rc = sc.get(&d_gtile, (size_t)(kg::kHDigits + 1) * n_chunks_p))) return rc;
+        if (kg::group_place_lds(gshift, gshift == 10) > t->place_lds[AA ? 1 : 0]) {
+            const size_t want_lds = kg::group_place_lds(gshift, gshift == 10);
+            HIP_TRY(hipFuncSetAttribute((const void *)kg::group_place_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want_lds));
+            t->place_lds[AA ? 1 : 0] = want_lds;
+        }
         if (groups_stride * 4u > t->hist_lds) {
             HIP_TRY(hipFuncSetAttribute((const void *)kg::hit_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(groups_stride * 4u)));
             t->hist_lds = groups_stride * 4u;
@@ -1179,9 +1185,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                                        gbase_c, n_groups, g0, 6u + gshift, gcur1_c, sortA_c, ucap, gtile_c);
                     hipLaunchKernelGGL((kg::hit_partition_kernel<false>), dim3(ogrid), dim3(kg::kHThreads), 0, s3, sortA_c, cused_c, ucur_c, ucap,
                                        gbase_c, n_groups, g0, 6u + gshift, gcur2_c, sortB_c, ucap, gtile_c);
-                    hipLaunchKernelGGL((kg::group_place_kernel<AA>), dim3(std::min(n_groups, 256u * 8u)), dim3(kg::kHThreads), (size_t)12 << gshift, s3,
-                                       sortB_c, gbase_c, n_groups, g0, gshift, (uint32_t)row_lo, (uint32_t)row_hi, d_geo, base_c, res->d_hits,
-                                       hits_cap, d_offs);
+                    const bool place_staged = gshift == 10 && env_u32("KG_PLACE_STAGED", 1u) != 0;
+                    hipLaunchKernelGGL((kg::group_place_kernel<AA>), dim3(std::min(n_groups, 256u * 8u)), dim3(kg::kHThreads),
+                                       kg::group_place_lds(gshift, place_staged), s3,
+                                       sortB_c, gbase_c, n_groups, g0, gshift, (uint32_t)row_lo, (uint32_t)row_hi, d_geo, (uint64_t)n_rows,
+                                       place_staged ? 1u : 0u, base_c, res->d_hits, hits_cap, d_offs);
                 }
                 HIP_TRY(hipGetLastError());
             }
