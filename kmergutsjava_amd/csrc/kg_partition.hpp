@@ -98,6 +98,21 @@ inline size_t scatter_lds_bytes(uint32_t n_buckets)
 // that bucket.  Regions are over-allocated (cap entries each, no counting pass); a group that does not fit its
 // region goes to the overflow list (skewed inputs), which is probed separately.  Layout of the entry array:
 // region (bucket b, workgroup w) = [ (b * n_wg + w) * cap , + fill[b * n_wg + w] ).
+// 16 bytes of a flushed group.  KG_SCATTER_NT: with the streaming hint (the entries are read once, a pass later, from HBM)
+#ifndef KG_SCATTER_NT
+#define KG_SCATTER_NT 1
+#endif
+__device__ __forceinline__ void store_entry_pair(uint64_t *dst, const ulonglong2 &v)
+{
+#if KG_SCATTER_NT
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+    u64x2 x; x.x = v.x; x.y = v.y;
+    __builtin_nontemporal_store(x, reinterpret_cast<u64x2 *>(dst));
+#else
+    *reinterpret_cast<ulonglong2 *>(dst) = v;
+#endif
+}
+
 template <bool AA>
 __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_scatter_kernel(
     const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t block_lo, uint32_t n_blocks /* of this launch */,
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
                     const uint32_t sub = (uint32_t)lane & 7u;
                     const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(buf + (size_t)fb * kGroup + 2 * sub);
                     uint64_t *base = (off >> 62) & 1 ? ovf_ent + (off & ~(1ull << 62)) : ent + off;
-                    *reinterpret_cast<ulonglong2 *>(base + 2 * sub) = v;
+                    store_entry_pair(base + 2 * sub, v);
                 }
             }
         }
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
                         const uint32_t sub = (uint32_t)lane & 7u;
                         const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(buf + (size_t)fb * kGroup + 2 * sub);
                         uint64_t *base = (off >> 62) & 1 ? ovf_ent + (off & ~(1ull << 62)) : ent + off;
-                        *reinterpret_cast<ulonglong2 *>(base + 2 * sub) = v;
+                        store_entry_pair(base + 2 * sub, v);
                     }
                 }
                 wave_sync();                                           // the copies above read buf[b] before it reopens
