@@ -206,6 +206,38 @@ __device__ __forceinline__ Entry load_entry(const TableView &t, uint64_t slot)
     return e;
 }
 
+// Streaming accesses: lists that are written once and read once, a pass later, from HBM carry the non-temporal hint so
+// that they do not push the tag pass's L2-resident tags (and each other) out of the 4 MiB L2 of their XCD.
+typedef uint32_t kg_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t kg_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stream_store16(void *dst, const void *src16)
+{
+    kg_u32x4 v;
+    __builtin_memcpy(&v, src16, 16);
+    __builtin_nontemporal_store(v, reinterpret_cast<kg_u32x4 *>(dst));
+}
+__device__ __forceinline__ void stream_store8(void *dst, uint64_t w)
+{
+    kg_u32x2 v; v.x = (uint32_t)w; v.y = (uint32_t)(w >> 32);
+    __builtin_nontemporal_store(v, reinterpret_cast<kg_u32x2 *>(dst));
+}
+__device__ __forceinline__ void stream_store_hit(kg_hit *dst, const kg_hit &h)      // 24 bytes, 8-byte aligned
+{
+    kg_u32x4 a; a.x = h.container; a.y = (uint32_t)h.from0InProt; a.z = (uint32_t)h.oI; a.w = (uint32_t)h.avgOffFromEnd;
+    kg_u32x2 b; b.x = (uint32_t)h.fI; b.y = __float_as_uint(h.functionWt);
+    __builtin_nontemporal_store(a, reinterpret_cast<kg_u32x4 *>(dst));
+    __builtin_nontemporal_store(b, reinterpret_cast<kg_u32x2 *>(reinterpret_cast<unsigned char *>(dst) + 16));
+}
+__device__ __forceinline__ kg_hit stream_load_hit(const kg_hit *src)
+{
+    const kg_u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const kg_u32x4 *>(src));
+    const kg_u32x2 b = __builtin_nontemporal_load(reinterpret_cast<const kg_u32x2 *>(reinterpret_cast<const unsigned char *>(src) + 16));
+    kg_hit h;
+    h.container = a.x; h.from0InProt = (int32_t)a.y; h.oI = (int32_t)a.z; h.avgOffFromEnd = (int32_t)a.w;
+    h.fI = (int32_t)b.x; h.functionWt = __uint_as_float(b.y);
+    return h;
+}
+
 // ---------------------------------------------------------------------------------------
 // genetic code (KGJ:88-93) folded with toAminoAcidOff (KGJ:111-175): codon -> 0..19, stop -> 20.
 // kCodon16[c1*4+c2] packs the four c3 codes, 5 bits each.

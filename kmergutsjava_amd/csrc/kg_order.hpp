@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kHThreads) void hit_partition_kernel(const kg_hit *
                 }
                 dr[k] = ~0u;
                 if (ok) {
-                    rec[k] = in[at];
+                    rec[k] = stream_load_hit(in + at);
                     const uint32_t g = (rec[k].container >> gs) - g0;
                     if (g < n_groups) {                              // (always; a record outside would be a kernel bug: dropped)
                         const uint32_t d = FIRST ? g / kHDigits : g % kHDigits;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kHThreads) void hit_partition_kernel(const kg_hit *
                 const uint32_t s0 = sbase[d] + (d >= 64 ? first_half : 0u);
                 const uint64_t o0 = gb[d];
                 const uint32_t n_ok = o0 >= out_cap ? 0u : (uint32_t)min((uint64_t)n, out_cap - o0);
-                for (uint32_t i = lane; i < 3u * n_ok; i += 64u) out64[o0 * 3u + i] = stage64[(uint64_t)s0 * 3u + i];
+                for (uint32_t i = lane; i < 3u * n_ok; i += 64u) stream_store8(out64 + o0 * 3u + i, stage64[(uint64_t)s0 * 3u + i]);
             }
             __syncthreads();                                         // stage / cnt / sbase / gb are rewritten by the next tile
         }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kHThreads) void group_place_kernel(const kg_hit *__
             for (uint32_t j = 0; j < kKeep; j++) {
                 const uint32_t k = j * kHThreads + tid;
                 if (k < n) {
-                    rk[j] = in[lo + k];
+                    rk[j] = stream_load_hit(in + lo + k);
                     atomicOr(&masks[(rk[j].container >> 6) & (R - 1u)], 1ull << (rk[j].container & 63u));
                 }
             }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kHThreads) void group_place_kernel(const kg_hit *__
             const uint64_t dst0 = chunk_base + lo;
             const uint32_t n_ok = dst0 >= hits_cap ? 0u : (uint32_t)min((uint64_t)n, hits_cap - dst0);
             uint64_t *out64 = reinterpret_cast<uint64_t *>(hits) + dst0 * 3u;
-            for (uint32_t i = tid; i < 3u * n_ok; i += kHThreads) out64[i] = lout[i];
+            for (uint32_t i = tid; i < 3u * n_ok; i += kHThreads) stream_store8(out64 + i, lout[i]);
             __syncthreads();                                // lout is rewritten by the next group
         }
     }

@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
                     const unsigned long long at = chunk_reserve(u, 64u, cand_used, cand_cursor, cand_cap, lane);
                     {
                         const ulonglong2 out = *reinterpret_cast<const ulonglong2 *>(stage + lane);
-                        if (at != ~0ull) *reinterpret_cast<ulonglong2 *>(cand + at + (uint32_t)lane) = out;
+                        if (at != ~0ull) stream_store16(cand + at + (uint32_t)lane, &out);
                     }
                     sfill -= 64u;
                     wave_sync();
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
         wave_sync();
         const CandRec out = stage[(uint32_t)lane < sfill ? lane : 0];
         const unsigned long long at = chunk_reserve(u, sfill, cand_used, cand_cursor, cand_cap, lane);
-        if (at != ~0ull && (uint32_t)lane < sfill) cand[at + (uint32_t)lane] = out;
+        if (at != ~0ull && (uint32_t)lane < sfill) stream_store16(cand + at + (uint32_t)lane, &out);
     }
     chunk_finish(u, cand_used, cand_cap, lane);
     flush_ran_off(ran_off, ctr, lane);
@@ -769,7 +769,10 @@ __global__ __launch_bounds__(256) void verify_kernel(
             const bool act = k0 + (uint32_t)lane < used;
             CandRec r;
             r.home = 0; r.quo = 0; r.id = 0; r.walked = 0;
-            if (act) r = cand[(uint64_t)c * kUChunk + k0 + lane];
+            if (act) {
+                const kg_u32x4 cv = __builtin_nontemporal_load(reinterpret_cast<const kg_u32x4 *>(cand + (uint64_t)c * kUChunk + k0 + lane));
+                r.home = cv.x; r.quo = cv.y; r.id = cv.z; r.walked = cv.w;
+            }
             const uint64_t quo = r.quo, home = r.home;
             const uint64_t val = quo * num_sigs + home;
             uint64_t s = home + (r.walked & kWalkedMask);
@@ -827,7 +830,7 @@ __global__ __launch_bounds__(256) void verify_kernel(
                     h.container = r.id;
                     h.from0InProt = 0;
                     h.oI = e.oI; h.avgOffFromEnd = e.avg; h.fI = e.fI; h.functionWt = e.wt;
-                    ulist[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = h;
+                    stream_store_hit(ulist + at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), h);
                 }
             }
         }
