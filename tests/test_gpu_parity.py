@@ -489,6 +489,35 @@ def test_partitioned_chunk_pipeline(hp, oracle, monkeypatch):
                 assert_same_records(r, ora, "aa chunks=%d" % chunks)
 
 
+def test_ordering_knobs_do_not_change_the_records(hp, oracle, monkeypatch):
+    """The ordered placement has a staged form (row geometry and output through LDS, groups of up to 1536 records) and a
+    direct one, and can run the chunks' orderings on streams of their own: same records either way, including groups that
+    are too dense for the staging buffer (every window of a stretch hits)."""
+    from kmergutsjava_amd import synth
+    monkeypatch.setenv("KG_PARTITION", "1")
+    monkeypatch.setenv("KG_PART_MIN_CHUNK_BLOCKS", "1")
+    monkeypatch.setenv("KG_PART_CHUNKS", "3")
+    keys = synth.random_keys(400_000, 91)
+    rec, placed = synth.build_table(keys, synth.payload_of(keys, 92, n_otu=5, n_fn=7), 1_000_003)
+    img = _img(rec)
+    lens = [120000, 0, 90000, 333, 150000, 70000, 24, 200000]
+    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    seq = synth.random_dna(int(off[-1]), 93)
+    sb = plant(seq.numpy().tobytes(), off, keys.tolist(), every=24)         # dense: 8 hits per row of the +0 frame, 8192 per group of 1024 rows
+    ora = oracle.run(img, sb, off, min_hits=2, max_gap=200, lookup_mode=1)
+    assert len(ora["hits"]) > 20_000
+    for env in ({}, {"KG_PLACE_STAGED": "0"}, {"KG_ORDER_STREAMS": "2"}, {"KG_ORDER_STREAMS": "4", "KG_PLACE_STAGED": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with hp.SignatureTable.from_bytes(img) as tab:
+            with tab.scan(sb, off, hp.Params(min_hits=2, max_gap=200)) as r:
+                assert r.stats["partitioned"] == 1
+                assert_same_records(r, ora, "ordering knobs %r" % (env,))
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_list_resize_and_rerun(hp, oracle, monkeypatch, strategy):
     """The hit / candidate lists (partitioned) and the staging area (direct) are sized from the hit rate seen so far;
     when they are too small the scan is re-run once with the exact size.  Force that path."""
