@@ -998,7 +998,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         // Round 2 (one tag wave per SIMD beside the scatter pass): 4 per CU 20.4 ms, 8 per CU 20.8 (profiles/r02_pipeline.md);
         // round 3 (two): 4 per CU 19.78 ms, 8 per CU 19.56, bench.py 20.5 -> 20.25 ms per step (profiles/r03_experiments.md).
         const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 8u) & ~7u;
-        const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 8u);
+        // verify workgroups: two per CU.  With eight (until round 3) the pass alone is 15 % faster, but its workgroups take all the
+        // registers an ending tag pass frees, and the next tag pass -- the critical chain -- starts behind them: stage 18.3 ->
+        // 18.15 ms, 125 Mbp shard 3.18 -> 3.10 (profiles/r03_experiments.md)
+        const uint32_t verify_grid = env_u32("KG_VERIFY_GRID", 256u * 2u);
         // The two kernels that usually find nothing to do (no low-complexity block set aside, no overflow group) sit on the
         // stage's critical chain -- in front of every tag pass and behind every verify pass -- and beside the other passes a
         // grid of 2048 / 1024 workgroups takes 0.1 / 0.35 ms just to be scheduled and leave (profiles/r03_kernel_stats.csv);
