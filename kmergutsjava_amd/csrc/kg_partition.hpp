@@ -61,6 +61,10 @@ constexpr int kMaxBuckets = 1024;
 #else
 #define KG_TAG_REGS
 #endif
+#ifndef KG_STAGE_FLUSH
+#define KG_STAGE_FLUSH 64
+#endif
+constexpr uint32_t kStageFlush = KG_STAGE_FLUSH;     // candidate records per flush of a tag wave's staging buffer (<= 64)
 constexpr int kProbeN = KG_PROBE_N;                  // queries per lane per iteration of the bucket probe
 constexpr uint32_t kUChunk = 512;           // records per reservation of the unordered hit list
 
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
     constexpr int N = kProbeN;
     const uint32_t lim32 = (uint32_t)limit;
     __shared__ uint32_t s_region;
-    __shared__ __attribute__((aligned(16))) CandRec s_stage[4][128];      // per wave: < 64 records waiting + <= 64 new ones
+    __shared__ __attribute__((aligned(16))) CandRec s_stage[4][kStageFlush + 64];      // per wave: < kStageFlush records waiting + <= 64 new ones
     CandRec *stage = s_stage[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
     uint32_t sfill = 0;                                                    // (wave-uniform)
     const int lane = threadIdx.x & 63;
@@ -710,19 +714,19 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
                     c.id = id[k]; c.walked = walked[k] | (((walkm >> k) & 1u) ? kWalkOn : 0u);
                     stage[sfill + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c;
                 }
-                sfill += (uint32_t)__popcll(m);                            // < 64 + 64
-                if (sfill >= 64u) {
+                sfill += (uint32_t)__popcll(m);                            // < kStageFlush + 64
+                while (sfill >= kStageFlush) {
                     // (one wave's LDS operations execute in program order: the fences only pin the compiler's order)
                     wave_sync();
-                    const unsigned long long at = chunk_reserve(u, 64u, cand_used, cand_cursor, cand_cap, lane);
-                    {
+                    const unsigned long long at = chunk_reserve(u, kStageFlush, cand_used, cand_cursor, cand_cap, lane);
+                    if ((uint32_t)lane < kStageFlush) {
                         const ulonglong2 out = *reinterpret_cast<const ulonglong2 *>(stage + lane);
                         if (at != ~0ull) stream_store16(cand + at + (uint32_t)lane, &out);
                     }
-                    sfill -= 64u;
+                    sfill -= kStageFlush;
                     wave_sync();
                     if ((uint32_t)lane < sfill) {                          // the remainder moves down
-                        const ulonglong2 rest = *reinterpret_cast<const ulonglong2 *>(stage + 64 + lane);
+                        const ulonglong2 rest = *reinterpret_cast<const ulonglong2 *>(stage + kStageFlush + lane);
                         *reinterpret_cast<ulonglong2 *>(stage + lane) = rest;
                     }
                     wave_sync();
