@@ -164,6 +164,12 @@ def main():
             got = ex.finish()              # rank 0: the records in global order (the hit records stay in HBM; their
             if with_hits and rank == 0:    # reordering is enqueued, not waited for: it runs beside the next scan)
                 last["hits_gathered"] = int(got["hits"].shape[0])
+            # rank 0's own share is a zero-copy view of the library's d_hits / d_chs, and finish() only ENQUEUED the kernels
+            # that read it (kg_restore_hits_device + torch slicing, on torch's current stream): the blocks may go back to the
+            # table's block cache -- whose rule is "idle when freed" -- only when that work has run.  (It still ran beside
+            # the scan that has just ended; the wait is for what is left of ~1 ms.)
+            if on_gpu and rank == 0:
+                torch.cuda.current_stream().synchronize()
             r.close()
 
     def step(with_hits=False):

@@ -24,7 +24,8 @@
  *   KG_VERIFY_GRID, KG_LOWC_GRID, KG_OVF_GRID, KG_ORDER_GRID, KG_ORDER_STREAMS, KG_PLACE_STAGED, KG_QIDX, KG_SCAN_GRID,
  *   KG_SCAN_RPG, KG_STAGE_CHUNK, KG_AGG_PIECES, KG_AGG_BLOCK_SHIFT: geometry of the
  *   scan strategies (kmerguts_hip.hip, scan_impl); results never depend on them.  KG_DEBUG: one stderr line per attempt.
- *   TEST HOOKS (used by tests/ only): KG_TEST_TINY_LISTS=1 starts the hit / candidate lists at one chunk, so that the
+ *   TEST HOOKS (used by tests/ only; inert unless the process set KG_ENABLE_TEST_HOOKS=1 before its FIRST kg_scan* -- that
+ *   one is read once, so a stray KG_TEST_* variable in a server's environment does nothing): KG_TEST_TINY_LISTS=1 starts the hit / candidate lists at one chunk, so that the
  *   resize-and-rerun path runs; KG_TEST_FAIL_ALLOC=n makes the n-th device allocation of the call fail with
  *   KG_ERR_NOMEM, so that the error paths can be checked for leaks (kg_table_live_device_bytes).
  */

@@ -235,6 +235,15 @@ uint32_t env_u32(const char *name, uint32_t dflt)
     return (end != v && x >= 0) ? (uint32_t)x : dflt;
 }
 
+// The two test hooks (KG_TEST_TINY_LISTS, KG_TEST_FAIL_ALLOC; include/kmerguts_hip.h) are read only when the process opted in
+// with KG_ENABLE_TEST_HOOKS=1 -- looked at ONCE, at the first scan: a stray KG_TEST_* variable in a server's environment
+// does nothing.
+uint32_t test_hook(const char *name)
+{
+    static const bool enabled = env_u32("KG_ENABLE_TEST_HOOKS", 0u) != 0;
+    return enabled ? env_u32(name, 0u) : 0u;
+}
+
 int dalloc(kg_table *t, void **p, size_t bytes)
 {
     if (t->fail_alloc_at && ++t->alloc_count == t->fail_alloc_at)
@@ -1013,7 +1022,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio * max_frac) + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         uint64_t ccap = ((uint64_t)((double)windows * (t->stage_ratio * 1.25 + 0.03) * max_frac) + list_slack + kg::kUChunk - 1) /
                         kg::kUChunk * kg::kUChunk;
-        if (env_u32("KG_TEST_TINY_LISTS", 0u)) ucap = ccap = kg::kUChunk;      // tests: force the resize-and-rerun path
+        if (test_hook("KG_TEST_TINY_LISTS")) ucap = ccap = kg::kUChunk;      // tests: force the resize-and-rerun path
         kg_hit *d_ulist = nullptr;
         uint32_t *d_cused = nullptr, *d_candused = nullptr;
         kg::CandRec *d_cand = nullptr;
@@ -1051,7 +1060,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 cl.p[6] = d_ghist; cl.words[6] = (uint64_t)groups_stride * n_chunks_p;
                 cl.p[7] = nullptr; cl.words[7] = 0;
                 if (levels == 2) { cl.n = 8; cl.p[7] = d_cur2; cl.words[7] = n_sub_total * n_chunks_p; }
-                const uint64_t most = std::max<uint64_t>(cl.words[6], 1) / 4;
+                uint64_t most = 1;                                      // the grid follows the LARGEST list (the kernel strides)
+                for (int k = 0; k < cl.n; k++) most = std::max(most, cl.words[k]);
+                most /= 4;
                 hipLaunchKernelGGL(kg::clear_many_kernel, dim3((uint32_t)std::min<uint64_t>(4096, (most + 255) / 256 + 1)), dim3(256), 0,
                                    t->stream, cl);
             }
@@ -1236,7 +1247,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             if (need_u <= ucap && need_c <= ccap) break;
             // a list was too small: now the exact need is known (masks are cleared and everything is redone)
             dfree(t, d_ulist); dfree(t, d_cused); dfree(t, d_cand); dfree(t, d_candused); dfree(t, res->d_hits);   // both streams are idle
+            dfree(t, d_sortA); dfree(t, d_sortB);                         // (the ordering buffers are sized by ucap as well)
             d_ulist = nullptr; d_cused = nullptr; d_cand = nullptr; d_candused = nullptr; res->d_hits = nullptr;
+            d_sortA = nullptr; d_sortB = nullptr;
             if (attempt == 2) return fail(KG_ERR_DEVICE, "hit list overflow after resize (internal error)");
             // which wave fills which reservation chunk differs from run to run: one partly used chunk per wave on top
             if (need_c > ccap) { ccap = (need_c + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk; ucap = std::max(ucap, ccap); }   // hits <= candidates
@@ -1273,7 +1286,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
     uint64_t stage_cap = (uint64_t)((double)windows * t->stage_ratio) + 4096 +
                          (uint64_t)scan_grid * kg::kWavesPerWG * stage_chunk;
     if (stage_cap > 0xFFFFFF00ull) stage_cap = 0xFFFFFF00ull;
-    if (env_u32("KG_TEST_TINY_LISTS", 0u)) stage_cap = 256;                    // tests: force the resize-and-rerun path
+    if (test_hook("KG_TEST_TINY_LISTS")) stage_cap = 256;                    // tests: force the resize-and-rerun path
     kg_hit *d_stage = nullptr;
     struct StageGuard { Scratch &sc; kg_hit *&p; ~StageGuard() { if (p) sc.adopt(p); } } stage_guard{sc, d_stage};
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -1376,7 +1389,7 @@ int scan_entry(kg_table *t, const kg_params *p, const uint8_t *seq, bool on_devi
         return fail(KG_ERR_BUSY, "another kg_scan* is in flight on this kg_table (one scan at a time per table; open a second table "
                                  "object for concurrent scans)");
     struct BusyGuard { kg_table *t; ~BusyGuard() { t->busy.store(0); } } busy_guard{t};
-    t->fail_alloc_at = env_u32("KG_TEST_FAIL_ALLOC", 0u);
+    t->fail_alloc_at = test_hook("KG_TEST_FAIL_ALLOC");
     t->alloc_count = 0;
     HIP_TRY(hipSetDevice(t->device));
     int64_t total = offsets[n_seqs] - offsets[0];

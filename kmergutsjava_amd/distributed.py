@@ -206,6 +206,10 @@ class RecordExchange:
         self.pending, self.with_hits, self.n_total_seqs, self.per = pending, with_hits, n_total_seqs, per
 
     def finish(self) -> Optional[dict]:
+        """Rank 0: the records in global order.  The hit records are restored by work ENQUEUED on torch's current stream
+        (kg_restore_hits_device, slicing) that reads the per-rank buffers -- rank 0's own are zero-copy views of the
+        library's result -- so the caller must let that stream run (synchronise it, or wait on an event) before it closes
+        the ScanResult the views belong to: the library's block cache takes blocks back as idle."""
         from . import _native as N
         got = self.pending.wait()
         self.pending = None

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the library's two test hooks (KG_TEST_TINY_LISTS, KG_TEST_FAIL_ALLOC) are inert unless the process opted in before its
+# first scan (include/kmerguts_hip.h)
+os.environ.setdefault("KG_ENABLE_TEST_HOOKS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

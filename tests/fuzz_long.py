@@ -7,6 +7,7 @@ import json
 import os
 import sys
 
+os.environ.setdefault("KG_ENABLE_TEST_HOOKS", "1")      # KG_TEST_TINY_LISTS workloads (include/kmerguts_hip.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

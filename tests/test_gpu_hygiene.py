@@ -73,3 +73,24 @@ def test_a_scan_that_fails_in_the_middle_leaves_nothing_behind(monkeypatch, mode
         assert failed >= 15
         with tab.scan(sb, off, hotpath.Params()) as r:
             assert (r.hits().tobytes(), r.calls().tobytes()) == want
+
+
+@pytest.mark.parametrize("levels", ["1", "2"])
+def test_resize_and_rerun_hands_every_list_block_back(monkeypatch, levels):
+    """KG_TEST_TINY_LISTS starts the hit / candidate lists (and with them the two ordering buffers) at one chunk: the
+    attempt is thrown away and redone with the exact sizes.  Every block of the first attempt has to be back in the
+    cache once the result is closed (round 3 leaked the ordering buffers of the first attempt until kg_table_close)."""
+    from kmergutsjava_amd import hotpath
+    img, sb, off = _workload()
+    monkeypatch.setenv("KG_PARTITION", "1")
+    monkeypatch.setenv("KG_PART_LEVELS", levels)
+    with hotpath.SignatureTable.from_bytes(img) as tab:
+        with tab.scan(sb, off, hotpath.Params()) as r0:
+            want = (r0.hits().tobytes(), r0.calls().tobytes())
+        assert tab.live_device_bytes() == 0
+        monkeypatch.setenv("KG_TEST_TINY_LISTS", "1")
+        for _ in range(2):
+            with tab.scan(sb, off, hotpath.Params()) as r:
+                assert r.stats["scan_launches"] >= 2, r.stats            # the resize-and-rerun path did run
+                assert (r.hits().tobytes(), r.calls().tobytes()) == want
+            assert tab.live_device_bytes() == 0, "%d bytes stayed live after a resized scan" % tab.live_device_bytes()

@@ -3,6 +3,7 @@
 DNA / protein, ragged and low-complexity sequences, parameters, forced chunking, tiny regions, tiny lists).  Every
 record kind and the event bytes must be byte-identical.  usage: fuzz_strategies.py [iterations] [seed]"""
 import json, os, sys
+os.environ.setdefault("KG_ENABLE_TEST_HOOKS", "1")      # KG_TEST_TINY_LISTS workloads (include/kmerguts_hip.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from kmergutsjava_amd import hotpath
