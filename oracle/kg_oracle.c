@@ -487,7 +487,9 @@ static int gather_sorted(const kgo_params *p, const kgo_hit_rec *all, int64_t n,
         int accept = !p->order_constraint || hits->n == 0;
         if (!accept) {                                          /* KGJ:490-494 */
             const kgo_hit_rec *last = &hits->a[hits->n - 1];
-            int32_t d = (ph->from0InProt - last->from0InProt) - (last->avgOffFromEnd - avgOffEnd);
+            /* Java int arithmetic wraps; signed overflow is undefined in C (found by the UBSan build, K17): unsigned */
+            int32_t d = (int32_t)(((uint32_t)ph->from0InProt - (uint32_t)last->from0InProt) -
+                                  ((uint32_t)last->avgOffFromEnd - (uint32_t)avgOffEnd));
             /* Math.abs(int): abs(MIN_VALUE) stays negative in Java */
             int32_t ad = d < 0 ? (int32_t)(0u - (uint32_t)d) : d;
             accept = (fI == last->fI) && (ad <= 20);
@@ -637,7 +639,7 @@ int kgo_run(const uint8_t *table, size_t table_nbytes, const kgo_params *p,
     /* KGJ:805-818 grouping: per query id in FASTA order; per container gatherHits */
     double t3 = now_s();
     /* gatherHits' stable sort by from0InProt (KGJ:460-465); positions are unique per container */
-    qsort(hits.a, (size_t)hits.n, sizeof *hits.a, hit_pos_cmp);
+    if (hits.n) qsort(hits.a, (size_t)hits.n, sizeof *hits.a, hit_pos_cmp);      /* (no hit at all: hits.a is NULL) */
     out->n_seqs = n_seqs; out->n_containers = n_cont;
     out->container_hit_start = (int64_t *)calloc((size_t)n_cont + 1, sizeof(int64_t));
     out->container_call_start = (int64_t *)calloc((size_t)n_cont + 1, sizeof(int64_t));

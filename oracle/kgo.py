@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkgoracle.so")
+# KGO_LIB_PATH: another build of the same source (tests/test_sanitizers.py loads oracle/libkgoracle_asan.so in a child process)
+LIB_PATH = os.environ.get("KGO_LIB_PATH") or os.path.join(HERE, "libkgoracle.so")
 
 HIT_DTYPE = np.dtype([("container", "<u4"), ("from0InProt", "<i4"), ("oI", "<i4"),
                       ("avgOffFromEnd", "<i4"), ("fI", "<i4"), ("functionWt", "<f4")])
@@ -41,7 +42,7 @@ _lib = None
 def build(force: bool = False) -> str:
     src = [os.path.join(HERE, "kg_oracle.c"), os.path.join(HERE, "kg_oracle.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
-        subprocess.run(["make", "-C", HERE, "-B", "libkgoracle.so"], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", HERE, "-B", os.path.basename(LIB_PATH)], check=True, stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 

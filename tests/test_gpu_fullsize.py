@@ -389,17 +389,23 @@ def test_config1_plumbing_at_its_stated_size(hp, oracle, strategy, monkeypatch):
     sb = seq.numpy().tobytes()
     monkeypatch.setenv("KG_PARTITION", "0" if strategy == "direct" else "1")
     monkeypatch.setenv("KG_PART_LEVELS", "2" if strategy == "partitioned2" else "1")
-    with hp.SignatureTable.from_bytes(img) as tab:
-        # the reference's defaults (-m 5 -g 200: functions are random here, so hardly any CALL) and a setting that calls a lot
-        for kw in (dict(), dict(min_hits=2, max_gap=600)):
-            ora = oracle.run(img, sb, off, aa=True, lookup_mode=0, **kw)
+    # the same keys with ONE function per protein for the signatures drawn from it: the reference's defaults then CALL
+    seq_c, off_c, rec_c, placed_c = synth.plumbing_config(coherent=True)
+    assert placed_c == placed and np.array_equal(off_c, off)
+    img_c = synth.table_image(rec_c)
+    for image, settings, min_calls in ((img, (dict(), dict(min_hits=2, max_gap=600)), 200), (img_c, (dict(),), 1000)):
+      with hp.SignatureTable.from_bytes(image) as tab:
+        # the reference's defaults (-m 5 -g 200: with functions hashed from the k-mer hardly any CALL -- that leg checks the
+        # hit records; with one function per protein thousands) and a setting that calls a lot on the hashed functions
+        for kw in settings:
+            ora = oracle.run(image, sb, off, aa=True, lookup_mode=0, **kw)
             assert ora["residues"] > 2_900_000 and len(ora["hits"]) > 100_000
-            assert not kw or len(ora["calls"]) > 200
+            assert (not kw and image is img) or len(ora["calls"]) > min_calls, len(ora["calls"])
             for counters in (True, False):           # (with the second level: the tag kernels / the home-index kernel)
                 with tab.scan(sb, off, hp.Params(aa=True, counters=counters, **kw)) as r:
                     assert_same_records(r, ora, "config 1 %s counters=%s %s" % (strategy, counters, kw))
                     if counters:
-                        o1 = oracle.run(img, sb, off, aa=True, lookup_mode=1, **kw)
+                        o1 = oracle.run(image, sb, off, aa=True, lookup_mode=1, **kw)
                         assert r.stats["windows_valid"] == o1["windows_valid"] and r.stats["slots_inspected"] == o1["slots_inspected"]
 
 
