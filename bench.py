@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
+HBM_MEASURED_GBS = 6290.0      # the same guide's measured streaming rate (SURVEY 8d asks for the fraction of both)
 
 
 def log(*a):
@@ -49,6 +50,8 @@ def main():
     ap.add_argument("--num-sigs", type=int, default=1_400_303_159, help="signature table slots (x 24 B)")
     ap.add_argument("--load", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="N = 1: skip the BASELINE configs 2 and 5 that are timed (a few seconds) behind the headline")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-threaded CPU row (0 = min(16, cores available); 1 = skip the row)")
     ap.add_argument("--cpu-sample-bp", type=int, default=100_000_000,
                     help="prefix of the contig list the CPU baseline is timed on (BASELINE.md section 3: >= 100 Mbp, "
@@ -70,6 +73,10 @@ def main():
                     help="N > 1, strong scaling: rank 0's share of the contigs relative to an equal share (rank 0 also receives every "
                          "rank's records and puts the hit records in global order: ~1 ms per step for 36.7 M records, tools/restore_time.py). "
                          "Default: 1 - 0.15 * N / 8 when the hit records are gathered, else 1")
+    ap.add_argument("--exchange-at-world-1", action="store_true",
+                    help="rehearsal (tests/test_gpu_rccl_world1.py): under a launcher with ONE rank, still create the process group "
+                         "and run every step's exchange through it -- init_process_group('nccl', device_id=...), the size gather and "
+                         "rank 0's restore on real RCCL without a second GPU")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     ap.add_argument("--strategy", choices=["auto", "direct", "partitioned"], default="auto",
                     help="scan strategy of the library (KG_PARTITION): auto picks partitioned probing for large inputs")
@@ -111,7 +118,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    multi = world > 1 or (args.exchange_at_world_1 and "WORLD_SIZE" in os.environ)      # the exchange runs
+    if multi:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -145,7 +153,7 @@ def main():
         lens, seq = all_lens, synth.random_dna(int(all_off[-1]), 302, dev, start=rank * args.total_bp)
     off = synth.offsets_of(lens)
     torch.cuda.synchronize()
-    log("[bench] rank %d: %d contigs, %d bp (%s)" % (rank, len(lens), int(off[-1]), "strong" if strong else "weak"))
+    log("[bench] rank %d: %d contigs, %d bp (%s)" % (rank, len(lens), int(off[-1]), "one GPU" if world == 1 else "strong" if strong else "weak"))
 
     params = hotpath.Params()                      # reference defaults: -m 5 -g 200
     gather_dev = comm_dev
@@ -158,11 +166,14 @@ def main():
     in_flight = []                                         # [(ScanResult, RecordExchange, with_hits)]
     last = {"hits_gathered": None}                         # hit records rank 0 received in the latest collected step
 
+    restore_ms = []                                        # rank 0: what finish() cost it per step (waits + reordering)
+
     def collect():
         while in_flight:
             r, ex, with_hits = in_flight.pop(0)
+            t_f = time.perf_counter()
             got = ex.finish()              # rank 0: the records in global order (the hit records stay in HBM; their
-            if with_hits and rank == 0:    # reordering is enqueued, not waited for: it runs beside the next scan)
+            if with_hits and rank == 0:    # reordering is enqueued on torch's stream, beside the scan that follows)
                 last["hits_gathered"] = int(got["hits"].shape[0])
             # rank 0's own share is a zero-copy view of the library's d_hits / d_chs, and finish() only ENQUEUED the kernels
             # that read it (kg_restore_hits_device + torch slicing, on torch's current stream): the blocks may go back to the
@@ -170,12 +181,14 @@ def main():
             # the scan that has just ended; the wait is for what is left of ~1 ms.)
             if on_gpu and rank == 0:
                 torch.cuda.current_stream().synchronize()
+            if rank == 0:
+                restore_ms.append((time.perf_counter() - t_f) * 1e3)
             r.close()
 
     def step(with_hits=False):
         r = tab.scan(None, off, params, device_ptr=seq.data_ptr())
         st = r.stats
-        if world > 1:
+        if multi:
             kinds = ("calls", "otu") + (("hits", "container_hit_start") if with_hits else ())
             local = {k: (r.device_view(k) if on_gpu else r.device_view(k).cpu()) for k in kinds}
             ex = kd.exchange_start(local, mine, n_total, 6, gather_dev, keep=r)
@@ -197,22 +210,23 @@ def main():
     b_alg = 0.5 + 24.0 * p_bar + 24.0 * h_bar
 
     for _ in range(args.warmup):
-        step(args.gather_hits and world > 1)
+        step(args.gather_hits and multi)
     collect()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     barrier()
+    del restore_ms[:]
     t1 = time.perf_counter()
     scan_ms, total_ms, agg_ms, order_ms = [], [], [], []
     pass_ms = {"scatter_until_last_chunk": [], "tag_verify_tail": []}
     hits = calls = 0
     partitioned = False
     for _ in range(args.steps):
-        st = step(args.gather_hits and world > 1)
+        st = step(args.gather_hits and multi)
         partitioned = bool(st["partitioned"])
         pass_ms["scatter_until_last_chunk"].append(st["ms_part_scatter"]); pass_ms["tag_verify_tail"].append(st["ms_part_verify"])
         scan_ms.append(st["ms_scan"]); total_ms.append(st["ms_total"])
@@ -223,9 +237,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t1
     hits_gathered_timed = last["hits_gathered"]
+    rank0_restore_ms = float(np.mean(restore_ms)) if restore_ms else None
 
     hits_probe = None
-    if world > 1 and not args.gather_hits:
+    if multi and not args.gather_hits:
         # outside the timed region: the same step with the per-rank hit buffers gathered to rank 0 as well
         step(True)
         collect()
@@ -238,7 +253,7 @@ def main():
         hits_probe = {"ms_per_step": (time.perf_counter() - t2) / 2 * 1e3}
 
     tot = torch.tensor([elapsed, float(residues), float(hits)], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if multi:
         mx = tot[:1].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot[1:].clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, residues_all, hits_all = float(mx[0]), float(sm[0]), float(sm[1])
@@ -268,7 +283,7 @@ def main():
             "unit": "residues/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong and world > 1 else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": (None if world == 1 else "strong" if strong else "weak"), "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
             "hits_per_s": hits_all * args.steps / elapsed,
             "config": {"workload": "%.3g Gbp contig mix (0.5 kbp..1.024 Mbp, uniform ACGT) %s, 6-frame translate + "
@@ -280,7 +295,7 @@ def main():
                        "total_bp_all_ranks": int(all_off[-1]) * (1 if strong else world),
                        "num_sigs": args.num_sigs, "residues_rank0": int(residues), "residues_all_ranks": int(residues_all),
                        "hits_rank0": int(hits), "hits_all_ranks": int(hits_all), "calls_rank0": int(calls),
-                       "exchange": (None if world == 1 else "per-rank %s buffers -> rank 0, %s point-to-point, device buffers, %s"
+                       "exchange": (None if not multi else "per-rank %s buffers -> rank 0, %s point-to-point, device buffers, %s"
                                     % ("CALL/OTU/hit" if args.gather_hits else "CALL/OTU",
                                        "RCCL" if args.backend == "nccl" else args.backend,
                                        "step i's transfers overlap scan i + 1 (all finished inside the timed region)"
@@ -291,9 +306,13 @@ def main():
                                             "too and put in global (container, from0InProt) order on the device",
                            hit_bytes_all_ranks=int(hits_all) * 24)),
                        "sink_share": (sink_share if world > 1 and strong else None),
+                       # rank 0's extra work per step, on the host clock: waiting for the step's transfers, CALL / OTU records
+                       # back in FASTA order, the hit records' segmented copy into global order (enqueued + waited for)
+                       "rank0_restore_ms": rank0_restore_ms,
                        "parallelism": "contig shards x%d, table replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "peak_measured": HBM_MEASURED_GBS, "frac_vs_measured_peak": achieved / HBM_MEASURED_GBS,
                          "achieved_step": achieved_step, "frac_step": achieved_step / HBM_PEAK_GBS,
                          "frac_note": "frac = algorithmic bytes / scan-stage time (HIP events on the library's streams); "
                                       "frac_step = the same bytes / ms_per_step (ordering, aggregation, records to host / "
@@ -315,16 +334,94 @@ def main():
             "stage_ms": {"scan": ms_scan, "order": float(np.mean(order_ms)), "aggregate": float(np.mean(agg_ms)),
                          "device_total": float(np.mean(total_ms))},
         }
+        host = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, rec, seq, off, tab)
+            host = host_table(args, rec)
+            out["cpu_baseline"] = cpu_baseline(args, rec, seq, off, tab, host)
+        if world == 1 and not args.no_extra_configs:
+            del seq
+            torch.cuda.empty_cache()
+            out["extra_configs"] = extra_configs(args, tab, host, dev)
         print(json.dumps(out), flush=True)
 
     tab.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, rec, seq, off, tab):
+def host_table(args, rec):
+    """The table image (header + records) in host memory: what the CPU oracle reads."""
+    import struct
+    t0 = time.time()
+    host = torch.empty(24 + args.num_sigs * 24, dtype=torch.uint8)
+    host[:24] = torch.frombuffer(bytearray(struct.pack("<qqq", args.num_sigs, 24, 1)), dtype=torch.uint8)
+    host[24:].view(torch.int32).view(args.num_sigs, 6).copy_(rec)
+    log("[bench] cpu_baseline: table copied to host in %.1f s" % (time.time() - t0))
+    return host
+
+
+def extra_configs(args, tab, host, dev):
+    """BASELINE configs 2 and 5 behind the headline, same ABI, same timing rule (inputs resident in HBM, CALL / OTU records
+    to the host): config 2 = 1000 x 100 kbp uniform DNA against the headline's table; config 5 = 100 Mbp assembled from
+    signature 8-mers of <= 32 functions / <= 8 OTUs against its own 20 000 003-slot table (8 M signatures) -- the workload
+    that loads processSetOfHits and the OTU votes (KGJ:385-455).  With the CPU baseline enabled, contigs drawn from every
+    quarter of each batch are checked against the oracle."""
+    from kmergutsjava_amd import hotpath, synth
+    steps, warm = max(5, args.steps), 2
+    rows = []
+
+    def run(name, tab_x, seq, off, image, note):
+        torch.cuda.synchronize()
+        for _ in range(warm):
+            with tab_x.scan(None, off, hotpath.Params(), device_ptr=seq.data_ptr()) as r:
+                r.calls(copy=False); r.otu(copy=False)
+        sts = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            with tab_x.scan(None, off, hotpath.Params(), device_ptr=seq.data_ptr()) as r:
+                r.calls(copy=False); r.otu(copy=False)
+                sts.append(r.stats)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        st = sts[-1]
+        row = {"workload": name, "note": note, "steps": steps, "ms_per_step": ms, "residues": int(st["residues"]),
+               "residues_per_s": st["residues"] / (ms * 1e-3), "hits": int(st["n_hits"]), "hits_per_s": st["n_hits"] / (ms * 1e-3),
+               "calls": int(st["n_calls"]), "calls_per_s": st["n_calls"] / (ms * 1e-3),
+               "strategy": "partitioned" if st["partitioned"] else "direct", "chunks": int(st["part_chunks"]),
+               "device_ms": {"scan": float(np.mean([x["ms_scan"] for x in sts])), "order": float(np.mean([x["ms_order"] for x in sts])),
+                             "aggregate": float(np.mean([x["ms_aggregate"] for x in sts])),
+                             "total": float(np.mean([x["ms_total"] for x in sts]))},
+               "parity_sample": None}
+        if image is not None:
+            from oracle import kgo
+            with tab_x.scan(None, off, hotpath.Params(), device_ptr=seq.data_ptr()) as r:
+                idx = synth.spread_sample(off, groups=4, per_group=6, max_bp_per_group=700_000)
+                sub_off = synth.offsets_of((off[1:] - off[:-1])[idx])
+                sub = torch.cat([seq[int(off[i]):int(off[i + 1])] for i in idx]).cpu().numpy()
+                o = kgo.run(image, sub, sub_off, lookup_mode=0)
+                got = r.subset(idx)
+                same = bool(all(got[k].tobytes() == o[k].tobytes() for k in ("hits", "calls", "otu")) and
+                            np.array_equal(got["container_hit_start"], o["container_hit_start"]) and
+                            np.array_equal(got["container_call_start"], o["container_call_start"]))
+            row["parity_sample"] = {"contigs": int(len(idx)), "bp": int(sub_off[-1]), "hits": int(len(o["hits"])),
+                                    "calls": int(len(o["calls"])), "identical": same}
+            assert same, "%s: GPU records differ from the oracle on the sample contigs" % name
+        log("[bench] extra config %s: %.3f ms/step, %d hits, %d CALLs, parity %s" % (name, ms, st["n_hits"], st["n_calls"], row["parity_sample"]))
+        rows.append(row)
+
+    seq2, off2 = synth.dna_uniform_config(1000, 100_000, 201, dev)
+    run("config 2", tab, seq2, off2, None if host is None else host.numpy(),
+        "BASELINE config 2: 1000 x 100 kbp uniform ACGT vs the %d-slot table, -m 5 -g 200" % args.num_sigs)
+    del seq2
+    seq5, off5, rec5 = synth.high_density_device(1000, 4167, 20_000_003, 8_000_000, 501, True, dev)
+    torch.cuda.synchronize()
+    with hotpath.SignatureTable.from_device_ptr(rec5.data_ptr(), 20_000_003, dev.index or 0, keepalive=rec5) as tab5:
+        run("config 5 (DNA)", tab5, seq5, off5, None if host is None else synth.table_image(rec5),
+            "BASELINE config 5: 1000 contigs x 4167 signature 8-mers (100 Mbp, back-translated), <= 32 functions / <= 8 OTUs, "
+            "20 000 003-slot table with 8 M signatures, -m 5 -g 200")
+    return rows
+
+
+def cpu_baseline(args, rec, seq, off, tab, host):
     """The C restatement of the reference algorithm (oracle/, literal sorted merge-join, 1 thread) timed on a prefix
     of the same workload against the same table, in batches of <= 20 M query k-mers (the reference's loss-free
     regime, KGJ:108, 832).  Its records are also the checker for the full-size GPU scan: the hit / CALL / OTU records
@@ -337,11 +434,6 @@ def cpu_baseline(args, rec, seq, off, tab):
     n = max(1, min(n, len(off) - 1))
     sample_off = off[:n + 1].copy()
     sample = seq[:int(sample_off[-1])].cpu().numpy()
-    t0 = time.time()
-    host = torch.empty(24 + args.num_sigs * 24, dtype=torch.uint8)
-    host[:24] = torch.frombuffer(bytearray(struct.pack("<qqq", args.num_sigs, 24, 1)), dtype=torch.uint8)
-    host[24:].view(torch.int32).view(args.num_sigs, 6).copy_(rec)
-    log("[bench] cpu_baseline: table copied to host in %.1f s" % (time.time() - t0))
     t0 = time.time()
     o = kgo.run(host.numpy(), sample, sample_off, lookup_mode=0)
     wall = time.time() - t0

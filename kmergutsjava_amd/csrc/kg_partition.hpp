@@ -64,6 +64,16 @@ constexpr int kMaxBuckets = 1024;
 #ifndef KG_STAGE_FLUSH
 #define KG_STAGE_FLUSH 64
 #endif
+// Rows of a DNA block (6: three phases x two strands) that the scatter pass keeps in registers and inserts together.
+// 6: all at once (twelve entry registers, six LDS atomics in flight per lane); 3: one strand at a time; 2: a third.
+#ifndef KG_SCATTER_RG
+#define KG_SCATTER_RG 6
+#endif
+// 1: the tag pass reads its 16 tags AT the home slot even when they straddle a 128-byte line (both lines are L2-resident
+// on this path: one more L2 request in 12 % of the probes, but the window always covers 16 slots: fewer undecided windows).
+#ifndef KG_TAG_STRADDLE
+#define KG_TAG_STRADDLE 0
+#endif
 constexpr uint32_t kStageFlush = KG_STAGE_FLUSH;     // candidate records per flush of a tag wave's staging buffer (<= 64)
 constexpr int kProbeN = KG_PROBE_N;                  // queries per lane per iteration of the bucket probe
 constexpr uint32_t kUChunk = 512;           // records per reservation of the unordered hit list
@@ -204,36 +214,48 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
         const uint32_t it0 = w * kScatterWaves + (uint32_t)wave;
         if (it0 < n_blocks) { bd_next = blocks[block_lo + it0]; load_block_chars<AA>(seq, bd_next, lane, raw_next); }
     }
+    constexpr int RG = AA ? 1 : KG_SCATTER_RG;        // rows per group
+    static_assert(ROWS % RG == 0, "KG_SCATTER_RG must divide 6");
     for (uint32_t iter = 0; iter < n_iter; iter++) {
         const uint32_t it = (iter * n_wg + w) * kScatterWaves + (uint32_t)wave;      // wave-uniform
-        uint64_t e[ROWS];
-        uint32_t bk[ROWS];
-        uint32_t pend = 0, vmask = 0;
-        if (it < n_blocks) {
-            const BlockDesc bd = bd_next;
+        BlockDesc bd;
+        const bool have = it < n_blocks;
+        if (have) {
+            bd = bd_next;
             uint32_t raw[4] = {raw_next[0], raw_next[1], raw_next[2], raw_next[3]};
             const uint32_t itn = it + n_wg * kScatterWaves;
             if (itn < n_blocks) { bd_next = blocks[block_lo + itn]; load_block_chars<AA>(seq, bd_next, lane, raw_next); }
             encode_chars<AA>(l, enc_tables, raw, lane);
+        }
+        bool lowc = false;                                                  // (wave-uniform) the block was set aside
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) {
+        for (int g0 = 0; g0 < ROWS; g0 += RG) {
+        uint64_t e[RG];
+        uint32_t bk[RG];
+        uint32_t pend = 0, vmask = 0;
+        if (have && !lowc) {
+#pragma unroll
+            for (int k = 0; k < RG; k++) {
+                const int r = g0 + k;
                 uint32_t hi, lo, q;
                 bool valid = row_halves<AA>(l, r, lane, bd, &hi, &lo);
                 const uint32_t slot = split_fast(hi, lo, num_sigs, m35, &q);
-                if (valid) vmask |= 1u << r;                            // query k-mers (KGJ:913-920), counted per block below
+                if (valid) vmask |= 1u << k;                            // query k-mers (KGJ:913-920), counted per block below
                 if (valid && slot >= limit32) ran_off = true;           // (truncated table file)
                 valid = valid && slot < limit32;                        // beyond the stream: never probed
-                bk[r] = slot >> shift;
+                bk[k] = slot >> shift;
                 const uint32_t low = (q << shift) | (slot & ((1u << shift) - 1u));
                 const uint32_t id = window_key<AA>(bd, block_lo + it, r, lane);
-                e[r] = ((uint64_t)id << 32) | low;
-                if (valid) pend |= 1u << r;
+                e[k] = ((uint64_t)id << 32) | low;
+                if (valid) pend |= 1u << k;
             }
-            wave_sync();   // the wave's encode scratch is reused by its next block
+            // the wave's encode scratch is reused by its next block -- and, below, the first 64 bytes of it (base codes: not
+            // read again once the codon codes are there) by the flush's rank -> lane map
+            if (g0 + RG == ROWS) wave_sync();
             // Low-complexity sequence (homopolymers, short tandem repeats): most windows of the block are one k-mer or
             // two, and pushing them through one 16-entry buffer serialises the whole workgroup on it.  Such a block
             // is not inserted here: it goes on a list for lowc_blocks_kernel, which appends its entries in bulk.
-            {
+            if (g0 == 0) {
                 const unsigned long long m0 = __ballot((pend & 1u) != 0);
                 if (__popcll(m0) >= 32) {
                     const uint32_t lead0 = (uint32_t)__builtin_amdgcn_readlane((int)bk[0], __builtin_ctzll(m0));
@@ -241,6 +263,8 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
                         if (lane == 0) lowc_blocks[atomicAdd(lowc_cursor, 1u)] = block_lo + it;
                         vmask = 0;                                         // counted by lowc_blocks_kernel
                         pend = 0;
+                        lowc = true;
+                        if (RG != ROWS) wave_sync();                       // (the later row groups are skipped)
                     }
                 }
             }
@@ -261,18 +285,18 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
         // wrong result.
         uint32_t done = 0, spins = 0;
         for (;;) {
-            uint32_t at[ROWS];
+            uint32_t at[RG];
 #pragma unroll
-            for (int r = 0; r < ROWS; r++)                             // the LDS atomics of all rows in flight together
+            for (int r = 0; r < RG; r++)                             // the LDS atomics of all rows in flight together
                 at[r] = (pend & (1u << r)) ? atomicAdd(&cnt[bk[r]], 1u) : kGroup;
             // (retry rounds look before they draw: a full buffer is polled with plain reads, so that waiting lanes
             //  neither serialise on the counter against the flushing wave nor run the counter round to zero)
 #pragma unroll
-            for (int r = 0; r < ROWS; r++)
+            for (int r = 0; r < RG; r++)
                 if (at[r] < kGroup) buf[(size_t)bk[r] * kGroup + at[r]] = e[r];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
-            for (int r = 0; r < ROWS; r++)
+            for (int r = 0; r < RG; r++)
                 if (at[r] < kGroup) {
                     pend &= ~(1u << r);
                     if (atomicAdd(&written[bk[r]], 1u) == kGroup - 1) done |= 1u << r;
@@ -286,7 +310,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
                 const int r0 = has ? __builtin_ctz(done) : 0;
                 uint32_t b = bk[0];
 #pragma unroll
-                for (int r = 1; r < ROWS; r++)
+                for (int r = 1; r < RG; r++)
                     if (r0 == r) b = bk[r];
                 unsigned long long dst_off = ~0ull;                    // entry index in ent (bit 62: in ovf_ent)
                 bool to_ovf = false;
@@ -302,11 +326,11 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
                 }
                 const unsigned long long movf = __ballot(to_ovf);      // region full: overflow list, one atomic per pass
                 if (movf) {
-                    uint32_t g0 = 0;
-                    if (lane == 0) g0 = atomicAdd(ovf_cursor, (uint32_t)__popcll(movf));
-                    g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0);
+                    uint32_t og = 0;
+                    if (lane == 0) og = atomicAdd(ovf_cursor, (uint32_t)__popcll(movf));
+                    og = (uint32_t)__builtin_amdgcn_readfirstlane((int)og);
                     if (to_ovf) {
-                        const uint32_t g = g0 + (uint32_t)__popcll(movf & ((1ull << lane) - 1ull));
+                        const uint32_t g = og + (uint32_t)__popcll(movf & ((1ull << lane) - 1ull));
                         if (g < ovf_cap) { ovf_bucket[g] = b; dst_off = (1ull << 62) | ((uint64_t)g * kGroup); }
                         else dst_off = ~0ull - 1;                     // dropped (the host falls back to direct probing)
                     }
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
                 const int rp = pend ? __builtin_ctz(pend) : 0;
                 uint32_t pb = bk[0];
 #pragma unroll
-                for (int r = 1; r < ROWS; r++)
+                for (int r = 1; r < RG; r++)
                     if (rp == r) pb = bk[r];
                 const volatile uint32_t *pc = &cnt[pb];
                 for (uint32_t polls = 0; polls < 64; polls++) {
@@ -352,12 +376,13 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
             // which would hand out the slots of a full buffer a second time.
             bool runaway = false;
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) runaway = runaway || (at[r] != kGroup && at[r] >= (1u << 28));
+            for (int r = 0; r < RG; r++) runaway = runaway || (at[r] != kGroup && at[r] >= (1u << 28));
             if (++spins > (1u << 20) || __ballot(runaway)) {
                 if (lane == 0) atomicOr(ovf_cursor + 2, 1u);           // sticky "protocol failure" word (ovf_cursor stays a group count)
                 break;
             }
         }
+        }   // row group
     }
     __syncthreads();
     // partial groups, padded with fillers
@@ -674,7 +699,12 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
                 id[k] = (uint32_t)(e >> 32);
                 const uint32_t home = bbase | (low[k] & smask);
                 fp[k] = tag_qs(low[k] >> shift, home);
+#if KG_TAG_STRADDLE
+                skip[k] = 0;
+                const uint32_t cur = home;                                       // (may straddle two L2-resident lines)
+#else
                 const uint32_t cur = (uint32_t)probe_window(home, &skip[k]);     // home - skip (skip != 0: the window straddles a line)
+#endif
                 if ((vmask >> k) & 1u) tg[k] = load_tags(tags + cur);
             }
             // a window that holds neither an empty slot nor the fingerprint (2 % of the probes: straddling windows,

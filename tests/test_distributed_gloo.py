@@ -20,6 +20,51 @@ def _free_port():
     return p
 
 
+def _worker8(rank, world, port, tmp):
+    """Eight ranks, the bench's geometry: weighted shards (the gathering rank scans less), a rank with an empty shard's worth
+    of hits is possible, exchange in its two halves, restore on rank 0."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from kmergutsjava_amd import distributed as kd, synth
+    from oracle import kgo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seq, off, rec, keys = synth.high_density_config(37, 30, 8009, 2500, seed=778, dna=True)
+        img = synth.table_image(rec)
+        sb = seq.numpy()
+        lens = np.diff(off)
+        shards = kd.shard_sequences(lens, world, [1.0 - 0.15 * world / 8.0] + [1.0] * (world - 1))     # bench.py's default sink share
+        assert sorted(np.concatenate(shards).tolist()) == list(range(len(lens))) and all(len(x) for x in shards)
+        mine = shards[rank]
+        s_seq, s_off = kd.take_shard(sb, off, mine)
+        loc = kgo.run(img, s_seq, s_off, lookup_mode=1)
+        local = {k: torch.from_numpy(loc[k].view(np.uint8).copy()) for k in ("calls", "otu", "hits")}
+        local["container_hit_start"] = torch.from_numpy(loc["container_hit_start"].copy())
+        pending = [kd.exchange_start(local, mine, len(lens), 6, "cpu") for _ in range(2)]      # two exchanges in flight (overlap)
+        for ex in pending:
+            got = ex.finish()
+            if rank == 0:
+                whole = kgo.run(img, sb, off, lookup_mode=1)
+                for k in ("calls", "container_call_start", "otu"):
+                    assert got[k].tobytes() == whole[k].tobytes(), k
+                assert got["hits"].numpy().tobytes() == whole["hits"].tobytes()
+                assert np.array_equal(got["container_hit_start"].numpy(), whole["container_hit_start"])
+                assert len(whole["calls"]) > 20 and len(whole["hits"]) > 500
+            else:
+                assert got is None
+        if rank == 0:
+            open(os.path.join(tmp, "ok8"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_and_gather_world8(tmp_path, oracle):
+    mp.spawn(_worker8, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    assert (tmp_path / "ok8").exists()
+
+
 def _worker(rank, world, port, dna, tmp):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
