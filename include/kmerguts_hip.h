@@ -21,7 +21,7 @@
  *   KG_PARTITION (0 direct / 1 partitioned whenever possible / 2 auto), KG_PART_LEVELS (1 / 2), KG_PART_SHIFT,
  *   KG_PART_SUBSHIFT, KG_PART_CHUNKS, KG_PART_MIN_CHUNK_BLOCKS, KG_PART_WGS, KG_PART_SLACK, KG_PART_CAP2,
  *   KG_PART_OVF_GROUPS, KG_PART_TAPER, KG_PROBE_GRID, KG_PROBE_GRAB, KG_PROBE2_GRID, KG_SUB_GRID, KG_SUB_RPI,
- *   KG_VERIFY_GRID, KG_LOWC_GRID, KG_OVF_GRID, KG_ORDER_GRID, KG_ORDER_STREAMS, KG_PLACE_STAGED, KG_QIDX, KG_SCAN_GRID,
+ *   KG_VERIFY_GRID, KG_LOWC_GRID, KG_OVF_GRID, KG_ORDER_GRID, KG_ORDER_STREAMS, KG_PLACE_STAGED, KG_QIDX, KG_BIDX, KG_SCAN_GRID,
  *   KG_SCAN_RPG, KG_STAGE_CHUNK, KG_AGG_PIECES, KG_AGG_BLOCK_SHIFT: geometry of the
  *   scan strategies (kmerguts_hip.hip, scan_impl); results never depend on them.  KG_DEBUG: one stderr line per attempt.
  *   TEST HOOKS (used by tests/ only; inert unless the process set KG_ENABLE_TEST_HOOKS=1 before its FIRST kg_scan* -- that
@@ -140,7 +140,9 @@ typedef struct kg_stats {
                                  /* at gaps > maxGap, where the reference's list restarts anyway: KGJ:477-484)       */
     int32_t part_levels;         /* partitioned only: 1 = tags probed in the L2 (bucket_tag_kernel), 2 = entries cut once more  */
                                  /* by sub-bucket and tags probed in LDS (kg_partition2.hpp), 3 = cut once more and looked up  */
-                                 /* in the table's home index held in LDS (sub_index_kernel)                                   */
+                                 /* in the table's home index held in LDS (sub_index_kernel), 4 = one level, the table's BYTE   */
+                                 /* home index probed in the L2 instead of the tags (bucket_index_kernel; the default for scans */
+                                 /* without KG_F_COUNTERS)                                                                      */
 } kg_stats;
 
 typedef struct kg_table  kg_table;

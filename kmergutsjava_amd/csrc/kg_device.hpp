@@ -1036,4 +1036,88 @@ __global__ void build_qidx_kernel(const uint8_t *entries, const uint8_t *tags, u
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Byte home index ("bidx", round 4): the home index above squeezed into ONE byte per slot, so that a bucket of it is as
+// large as a bucket of tags (2 MiB for 2^21 slots: resident in an XCD's L2) and the ONE-level tag pass can probe it
+// instead of the tags: one byte load per query, no fingerprint, no 16-tag window, no walk -- and, for the KmerGuts table,
+// no false candidate and no undecided window (the tag pass leaves 65 M candidates per Gbp for 36.7 M hits: fingerprint
+// collisions and, above all, home slots inside long occupied runs, whose 16-tag window decides nothing).
+// The byte lists the quotient CLASSES c = q % 19 of the keys homed at h that the reference's lookup can find (those in the
+// occupied run that starts at h, KGJ:944-1034):
+//     0          no such key: a query with home slot h is a miss for certain
+//     1..19      one class: c = code - 1
+//     20..190    two classes c1 < c2 (171 pairs), bidx_pair_code
+//     191..254   three or more classes, hashed to six bits: bit (c % 6) of (code - 191) is set for every listed class; a query
+//                whose bit is clear is a miss for certain, one whose bit is set a candidate for the generic walk (1.4 % of
+//                the home slots at load 0.5, under half of the queries there)
+//     255        the run was not walked to its end (longer than kQidxMaxWalk): every query is a candidate for the walk
+// With numSigs > 20^8 / 19 (the KmerGuts table: 1.4e9 slots, quotients 0..18) a class IS the quotient and codes 1..190 are
+// exact: listed = in the table for certain (kScanOn: the verify pass scans the records from the home slot).  Smaller tables
+// fold their quotients into the 19 classes: "not listed" stays a certain miss, "listed" becomes a candidate for the walk.
+constexpr uint32_t kBidxClasses = 19, kBidxPair0 = 20, kBidxHash0 = 191, kBidxMore = 255;
+constexpr uint32_t kBidxInexact = 0x80000000u;      // flag in the decoded word: a listed class is a candidate, not a hit
+
+__host__ __device__ constexpr uint32_t bidx_pair_code(uint32_t c1, uint32_t c2)      // c1 < c2 < 19
+{
+    return kBidxPair0 + c1 * 19u - c1 * (c1 + 1u) / 2u + (c2 - c1 - 1u);
+}
+static_assert(bidx_pair_code(0, 1) == 20 && bidx_pair_code(0, 18) == 37 && bidx_pair_code(1, 2) == 38 && bidx_pair_code(17, 18) == 190,
+              "pair codes must fill 20..190");
+
+// byte -> the 19 class bits (+ kBidxInexact)
+__device__ __forceinline__ uint32_t bidx_decode(uint32_t code)
+{
+    if (code == 0) return 0u;
+    if (code < kBidxPair0) return 1u << (code - 1u);
+    if (code < kBidxHash0) {
+        uint32_t c1 = 0;
+        while (code >= bidx_pair_code(c1, c1 + 1u) + (18u - c1)) c1++;
+        const uint32_t c2 = c1 + 1u + (code - bidx_pair_code(c1, c1 + 1u));
+        return (1u << c1) | (1u << c2);
+    }
+    if (code == kBidxMore) return 0x7FFFFu | kBidxInexact;
+    const uint32_t m6 = code - kBidxHash0;
+    uint32_t m = 0;
+    for (uint32_t c = 0; c < kBidxClasses; c++) m |= ((m6 >> (c % 6u)) & 1u) << c;
+    return m | kBidxInexact;
+}
+
+__device__ __forceinline__ uint32_t bidx_encode(uint32_t class_mask, bool complete)
+{
+    if (!complete) return kBidxMore;
+    const uint32_t n = (uint32_t)__popc(class_mask);
+    if (n == 0) return 0u;
+    const uint32_t c1 = (uint32_t)__builtin_ctz(class_mask);
+    if (n == 1) return 1u + c1;
+    if (n == 2) return bidx_pair_code(c1, 31u - (uint32_t)__builtin_clz(class_mask));
+    const uint32_t m6 = (class_mask | (class_mask >> 6) | (class_mask >> 12) | (class_mask >> 18)) & 63u;
+    return kBidxHash0 + m6;
+}
+
+__global__ void build_bidx_kernel(const uint8_t *entries, const uint8_t *tags, uint64_t limit, uint64_t n_idx, uint64_t num_sigs,
+                                  uint64_t magic, uint8_t *idx)
+{
+    TableView tab;
+    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic; tab.m35 = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n_idx; h += stride) {
+        uint32_t mask = 0;
+        bool complete = true;
+        if (h < limit && tags[h] != kTagEmpty) {
+            uint64_t j = h;
+            for (; j < limit && j - h < kQidxMaxWalk; j++) {
+                if (tags[j] == kTagEmpty) break;
+                const uint2 a = *reinterpret_cast<const uint2 *>(entries + j * 24);
+                const int64_t key = (int64_t)(((uint64_t)a.y << 32) | a.x);
+                if (key < 0) continue;                      // occupied, matches no query (KGJ:1000-1004)
+                uint64_t q;
+                if (split_value((uint64_t)key, tab, &q) != h) continue;
+                mask |= 1u << (uint32_t)(q % kBidxClasses);
+            }
+            if (j < limit && j - h >= kQidxMaxWalk) complete = false;
+        }
+        idx[h] = (uint8_t)bidx_encode(mask, complete);
+    }
+}
+
 }  // namespace kg

@@ -778,6 +778,127 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
     }
 }
 
+// The same pass on the table's BYTE HOME INDEX (kg_device.hpp, build_bidx_kernel) instead of the tags: hand-outs, entry
+// stream and candidate staging as in bucket_tag_kernel, but per entry ONE byte load out of the L2 (a bucket of the index is
+// as large as a bucket of tags), one LDS read that decodes it (256-word table) and a bit test with the query's quotient:
+//   listed, exact code      -> candidate flagged kScanOn: the key IS in the occupied run from its home slot; the verify pass
+//                              scans the records there and takes the payload
+//   listed, hashed / inexact -> candidate flagged kWalkOn: the verify pass walks the tags (generic)
+//   not listed              -> a miss for certain; the reference's walk ends with the stream iff the home slot lies in the
+//                              occupied run at its end (home >= tail_start: lookup_ran_off, KGJ:799-802)
+// No fingerprint, no 16-tag window, no undecided window: ~40 VALU per entry against ~126, and 36.7 M + 6 M candidates per Gbp
+// of the bench against 65 M.  Not used by KG_F_COUNTERS scans (slots_inspected needs the walk: bucket_tag_kernel<true>).
+__global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
+    const uint8_t *__restrict__ bidx, uint32_t exact /* classes are quotients */, uint32_t tail_start,
+    const uint64_t *__restrict__ ent, const uint32_t *__restrict__ fill, uint32_t n_regions, uint32_t cap, uint32_t n_buckets,
+    uint32_t shift, uint32_t grab /* entry slots per hand-out, multiple of 256 * kProbeN */,
+    uint32_t *next_region /* ticket counter of group x at [32 * x], zeroed */,
+    CandRec *__restrict__ cand, uint32_t *__restrict__ cand_used, unsigned long long *cand_cursor, uint64_t cand_cap,
+    unsigned long long *ctr)
+{
+    constexpr int N = kProbeN;
+    __shared__ uint32_t s_region;
+    __shared__ uint32_t s_lut[256];
+    __shared__ __attribute__((aligned(16))) CandRec s_stage[4][kStageFlush + 64];      // per wave: < kStageFlush records waiting + <= 64 new ones
+    CandRec *stage = s_stage[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+    uint32_t sfill = 0;                                                    // (wave-uniform)
+    const int lane = threadIdx.x & 63;
+    bool ran_off = false;
+    UListState u;
+    u.base = 0; u.used = kUChunk; u.have = false;      // "full": the first append takes a chunk
+    s_lut[threadIdx.x] = bidx_decode(threadIdx.x);      // (256 threads; the loop's first barrier publishes it)
+
+    const uint32_t kGrab = grab;
+    const uint32_t grabs_per_region = (cap + kGrab - 1) / kGrab;
+    const uint32_t n_grabs = n_regions * grabs_per_region;
+    const uint32_t xg = blockIdx.x & 7u;
+    const uint32_t n_tickets = xg < n_buckets ? ((n_buckets - xg + 7u) / 8u) * n_grabs : 0u;
+    const uint32_t all_walk = exact ? 0u : kBidxInexact;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_region = atomicAdd(&next_region[xg * 32u], 1u);
+        __syncthreads();
+        const uint32_t tk = s_region;
+        if (tk >= n_tickets) break;                 // the group's buckets are exhausted
+        const uint32_t b = xg + 8u * (tk / n_grabs), g = tk % n_grabs;
+        const uint32_t w = g / grabs_per_region, g0 = (g % grabs_per_region) * kGrab;
+        const uint32_t fraw = fill[(uint64_t)b * n_regions + w];
+        uint32_t n = cap;                               // until the fill has arrived
+        const uint64_t *src = ent + ((uint64_t)b * n_regions + w) * cap;
+        const uint32_t smask = (1u << shift) - 1u, bbase = b << shift;
+        for (uint32_t c0 = g0; c0 < n && c0 < g0 + kGrab; c0 += 256u * N) {
+            const uint32_t bound = n;
+            uint64_t ev[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const uint32_t i = c0 + (uint32_t)k * 256u + threadIdx.x;
+                ev[k] = i < bound ? __builtin_nontemporal_load(src + i) : kEntInvalid;
+            }
+            if (c0 == g0) {
+                uint32_t f = fraw;
+                asm volatile("; fill first used here" : "+s"(f));       // (keeps the scalar wait behind the entry loads)
+                n = min(f, cap);                                        // (bulk appends may have run past the region)
+            }
+            uint32_t code[N], vmask = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                if (c0 + (uint32_t)k * 256u + threadIdx.x >= n) ev[k] = kEntInvalid;
+                code[k] = 0;
+                if (ev[k] != kEntInvalid) {
+                    vmask |= 1u << k;
+                    code[k] = bidx[bbase | ((uint32_t)ev[k] & smask)];      // the home slot's byte, out of the L2
+                }
+            }
+            uint32_t candm = 0, walkm = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const uint32_t q = (uint32_t)ev[k] >> shift;
+                const uint32_t wd = s_lut[code[k]] | all_walk;
+                const uint32_t c = exact ? q : q % kBidxClasses;
+                if ((vmask >> k) & 1u) {
+                    if ((wd >> c) & 1u) { candm |= 1u << k; if (wd & kBidxInexact) walkm |= 1u << k; }
+                    else if ((bbase | ((uint32_t)ev[k] & smask)) >= tail_start) ran_off = true;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const unsigned long long m = __ballot((candm >> k) & 1u);
+                if (!m) continue;                                          // (uniform)
+                if ((candm >> k) & 1u) {
+                    CandRec c;
+                    c.home = bbase | ((uint32_t)ev[k] & smask); c.quo = (uint32_t)ev[k] >> shift;
+                    c.id = (uint32_t)(ev[k] >> 32); c.walked = ((walkm >> k) & 1u) ? kWalkOn : kScanOn;
+                    stage[sfill + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c;
+                }
+                sfill += (uint32_t)__popcll(m);                            // < kStageFlush + 64
+                while (sfill >= kStageFlush) {
+                    wave_sync();
+                    const unsigned long long at = chunk_reserve(u, kStageFlush, cand_used, cand_cursor, cand_cap, lane);
+                    if ((uint32_t)lane < kStageFlush) {
+                        const ulonglong2 out = *reinterpret_cast<const ulonglong2 *>(stage + lane);
+                        if (at != ~0ull) stream_store16(cand + at + (uint32_t)lane, &out);
+                    }
+                    sfill -= kStageFlush;
+                    wave_sync();
+                    if ((uint32_t)lane < sfill) {                          // the remainder moves down
+                        const ulonglong2 rest = *reinterpret_cast<const ulonglong2 *>(stage + kStageFlush + lane);
+                        *reinterpret_cast<ulonglong2 *>(stage + lane) = rest;
+                    }
+                    wave_sync();
+                }
+            }
+        }
+    }
+    if (sfill) {                                                           // the wave's last, partial group
+        wave_sync();
+        const CandRec out = stage[(uint32_t)lane < sfill ? lane : 0];
+        const unsigned long long at = chunk_reserve(u, sfill, cand_used, cand_cursor, cand_cap, lane);
+        if (at != ~0ull && (uint32_t)lane < sfill) stream_store16(cand + at + (uint32_t)lane, &out);
+    }
+    chunk_finish(u, cand_used, cand_cap, lane);
+    flush_ran_off(ran_off, ctr, lane);
+}
+
 // Verify pass: one wave per candidate chunk at a time, one lane per candidate.
 template <bool AA, bool COUNTERS>
 __global__ __launch_bounds__(256) void verify_kernel(

@@ -186,6 +186,8 @@ struct kg_table {
     uint16_t *d_qidx = nullptr;         // home index (kg_device.hpp, build_qidx_kernel) or null when the table is not eligible
     uint64_t n_qidx = 0;                // its length in words (limit rounded up, filled with "no key")
     bool qidx_exact = false;            // every quotient < 31: a listed quotient is a hit for certain
+    uint8_t *d_bidx = nullptr;          // byte home index (kg_device.hpp, build_bidx_kernel): 1 byte per slot, limit + 64 bytes
+    bool bidx_exact = false;            // every quotient < 19: its classes are quotients
     uint64_t tail_start = 0;            // first slot of the occupied run that ends at the end of the record stream
     int64_t num_sigs = 0, entry_size = 0, version = 0;
     uint64_t limit = 0;          // complete 24-byte records present
@@ -289,6 +291,16 @@ int table_finish(kg_table *t)
         const uint64_t wantq = (t->n_qidx + 255) / 256;
         hipLaunchKernelGGL(kg::build_qidx_kernel, dim3((uint32_t)std::min<uint64_t>(wantq, 256ull * 32)), dim3(256), 0, t->stream,
                            t->d_entries, t->d_tags, t->limit, t->n_qidx, (uint64_t)t->num_sigs, t->magic, t->d_qidx);
+        HIP_TRY(hipGetLastError());
+    }
+    // the byte home index: what the one-level tag pass probes instead of the tags (KG_BIDX=0 leaves it out)
+    t->bidx_exact = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1 <= kg::kBidxClasses;
+    if (t->m35 != 0 && t->limit > 0 && env_u32("KG_BIDX", 1u) != 0) {
+        const uint64_t n_bidx = t->limit + kg::kTagPad;
+        HIP_TRY(hipMalloc((void **)&t->d_bidx, n_bidx));
+        const uint64_t wantb = (n_bidx + 255) / 256;
+        hipLaunchKernelGGL(kg::build_bidx_kernel, dim3((uint32_t)std::min<uint64_t>(wantb, 256ull * 32)), dim3(256), 0, t->stream,
+                           t->d_entries, t->d_tags, t->limit, n_bidx, (uint64_t)t->num_sigs, t->magic, t->d_bidx);
         HIP_TRY(hipGetLastError());
     }
     unsigned long long occ[2] = {0, 0};
@@ -564,6 +576,7 @@ void kg_table_close(kg_table *t)
     if (t->own_entries && t->d_entries) (void)hipFree(t->d_entries);
     if (t->d_tags) (void)hipFree(t->d_tags);
     if (t->d_qidx) (void)hipFree(t->d_qidx);
+    if (t->d_bidx) (void)hipFree(t->d_bidx);
     t->cache.release_all();
     t->pins.release_all();
     if (t->h_pin) (void)hipHostFree(t->h_pin);
@@ -967,6 +980,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if (sshift + 6 < part_shift) sshift = part_shift - 6;                         // at most kMaxSub sub-buckets per bucket
         if (sshift + 1 > part_shift) sshift = part_shift - 1;
         if (levels != 2 || part_shift < 9 || sshift < 8) levels = 1;
+        // one level: the tag pass on the byte home index instead of the tags (bucket_index_kernel) unless the scan counts the
+        // slots it inspects (the walk the index avoids) or KG_BIDX=0
+        const bool use_bidx = levels == 1 && t->d_bidx != nullptr && !counters && env_u32("KG_BIDX", 1u) != 0;
         const uint32_t n_sub = levels == 2 ? 1u << (part_shift - sshift) : 0u;
         const uint64_t n_sub_total = (uint64_t)part_buckets * n_sub;                  // sub-bucket arrays per chunk
         const uint32_t n_items2 = levels == 2 ? (uint32_t)((t->limit + (1ull << sshift) - 1) >> sshift) : 0u;
@@ -1126,7 +1142,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                     else if (counters) hipLaunchKernelGGL((kg::sub_probe_kernel<true>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
                     else hipLaunchKernelGGL((kg::sub_probe_kernel<false>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
 #undef KG_TAG2_ARGS
-                } else if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
+                } else if (use_bidx)
+                    hipLaunchKernelGGL(kg::bucket_index_kernel, dim3(probe_grid), dim3(256), 0, s2, t->d_bidx, t->bidx_exact ? 1u : 0u,
+                                       (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent_c, fill_c, n_wg, cap, part_buckets,
+                                       part_shift, probe_grab, next_c, cand_c, candused_c, ccur_c, ccap, d_ctr);
+                else if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
                 else hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
                 HIP_TRY(hipEventRecord(t->pev[2 * c + 1], s2));
                 HIP_TRY(hipStreamWaitEvent(s3, t->pev[2 * c + 1], 0));
@@ -1270,7 +1290,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             part_done = true;
             st.partitioned = 1;
             st.part_chunks = (int32_t)n_chunks_p; st.part_buckets = (int32_t)part_buckets; st.part_shift = (int32_t)part_shift;
-            st.part_levels = (int32_t)(levels == 2 && use_qidx ? 3 : levels);
+            st.part_levels = (int32_t)(levels == 2 && use_qidx ? 3 : use_bidx ? 4 : levels);
         }
     }
     if (!part_done) {

@@ -32,7 +32,8 @@ def assert_same_records(gpu, ora, what=""):
     if mode == "1" and gpu.stats["n_blocks"] > 0 and os.environ.get("KG_PART_OVF_GROUPS") is None and os.environ.get("KG_PART_SLACK") is None and _partition_fits(gpu.stats):
         assert gpu.stats["partitioned"] == 1, what + ": the partitioned strategy fell back to direct probing"
     if gpu.stats["partitioned"] == 1:
-        want = 1
+        # one level: 4 = the byte home index probed in the L2 (scans without KG_F_COUNTERS), 1 = the tags
+        want = 4 if os.environ.get("KG_BIDX", "1") != "0" and gpu.stats["windows_valid"] < 0 else 1
         if os.environ.get("KG_PART_LEVELS") == "2" and gpu.stats["part_shift"] >= 9:
             # 3 = home index in LDS (no counters kernel: KG_F_COUNTERS scans keep the tag kernels), 2 = tags in LDS
             want = 3 if os.environ.get("KG_QIDX", "1") != "0" and gpu.stats["windows_valid"] < 0 else 2

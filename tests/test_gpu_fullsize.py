@@ -423,7 +423,13 @@ def test_two_level_scan_and_home_index_at_full_size(hp, oracle, full_table, monk
     monkeypatch.delenv("KG_PARTITION", raising=False)
     monkeypatch.setenv("KG_PART_LEVELS", "1")
     with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as r1:
-        assert r1.stats["partitioned"] == 1 and r1.stats["part_levels"] == 1
+        assert r1.stats["partitioned"] == 1 and r1.stats["part_levels"] == 4          # one level, byte home index (the default)
+        monkeypatch.setenv("KG_BIDX", "0")
+        with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as r0:
+            assert r0.stats["part_levels"] == 1 and r0.stats["fallback"] == 0, r0.stats
+            _same_on_device(r1, r0, "one level: byte home index vs tags")
+            assert r0.stats["lookup_ran_off"] == r1.stats["lookup_ran_off"]
+        monkeypatch.delenv("KG_BIDX")
         monkeypatch.setenv("KG_PART_LEVELS", "2")
         with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as r3:
             assert r3.stats["part_levels"] == 3 and r3.stats["fallback"] == 0, r3.stats
@@ -439,15 +445,17 @@ def test_two_level_scan_and_home_index_at_full_size(hp, oracle, full_table, monk
             assert (rc.stats["windows_valid"], rc.stats["slots_inspected"]) == (r2.stats["windows_valid"], r2.stats["slots_inspected"])
 
 
-def test_home_index_on_hand_made_clusters_in_a_full_size_table(hp, oracle, monkeypatch):
+@pytest.mark.parametrize("n", [900_000_011, 1_400_000_029])
+def test_home_index_on_hand_made_clusters_in_a_full_size_table(hp, oracle, monkeypatch, n):
     """The exact home index (numSigs > 20^8 / 31) on the cases it could get wrong, planted by hand into an otherwise
     empty 900 000 011-slot table and queried as proteins: four and five keys sharing one home slot (the 'more' bit), a key
     behind a NEGATIVE whichKmer, a key behind a hole (not reachable), a key in front of its home slot (not reachable), the
     same key twice in one run (the first one wins), and keys in the occupied run that ends at the end of the record stream
     (lookup_ran_off).  Oracle: literal merge-join and direct probing."""
+    # n = 900 000 011: quotients up to 28 -- exact for the 16-bit index (< 31), folded into classes for the byte index (>= 19);
+    # n = 1 400 000 029: quotients up to 18 -- exact for both (the KmerGuts table's regime)
     from kmergutsjava_amd import synth
     import kat_cases as K
-    n = 900_000_011
     dev = torch.device("cuda", 0)
     rec = torch.empty((n, 6), dtype=torch.int32, device=dev)
     empty = 20 ** 8 + 1
@@ -480,6 +488,15 @@ def test_home_index_on_hand_made_clusters_in_a_full_size_table(hp, oracle, monke
     h = 17000                                      # the same key twice in one run: the first record's payload
     put(h, 6 * n + h, 24, 2); put(h + 1, 6 * n + h, 25, 2)
     queries.append((6 * n + h, 24))
+    h = 21000                                      # two keys at one home slot (the byte index's pair codes), a third quotient absent
+    put(h, 3 * n + h, 31, 2); put(h + 1, 11 * n + h, 32, 2)
+    queries.append((3 * n + h, 31)); queries.append((11 * n + h, 32)); queries.append((5 * n + h, None))
+    h = 25000                                      # three keys (the byte index hashes them to six bits): quotients 0, 1, 2
+    for q in range(3):
+        put(h + q, q * n + h, 33 + q, 2)
+        queries.append((q * n + h, 33 + q))
+    queries.append((6 * n + h, None))              # 6 % 6 = 0: its bit is set -> a candidate the walk refutes
+    queries.append((9 * n + h, None))              # 9 % 6 = 3: bit clear -> a certain miss
     h = n - 3                                      # the run that ends with the stream: found ones are found, a miss runs off
     put(h, 1 * n + h, 26, 2); put(h + 1, 2 * n + h, 27, 2); put(h + 2, 0 * n + h + 2, 28, 2)
     queries.append((2 * n + h, 27)); queries.append((0 * n + h + 2, 28))
@@ -506,11 +523,12 @@ def test_home_index_on_hand_made_clusters_in_a_full_size_table(hp, oracle, monke
                 got = sorted({int(x["oI"]) for x in ora0["hits"][ora0["hits"]["container"] == k]})
                 assert got == ([oi] if oi is not None else []), (k, v, got, oi)
             assert bool(ora0["lookup_aborted"]) == with_run_off
-            for levels, counters in (("1", False), ("2", True), ("2", False)):
+            for levels, counters in (("1", False), ("1", True), ("2", True), ("2", False)):
                 monkeypatch.setenv("KG_PART_LEVELS", levels)
                 with tab.scan(sb, off, hp.Params(aa=True, min_hits=2, counters=counters)) as r:
                     assert r.stats["partitioned"] == 1
-                    assert r.stats["part_levels"] == (1 if levels == "1" else 2 if counters else 3)
+                    # 4: the byte home index in the L2, 1: the tags in the L2, 3: the 16-bit home index in LDS, 2: the tags in LDS
+                    assert r.stats["part_levels"] == ((1 if counters else 4) if levels == "1" else 2 if counters else 3)
                     assert r.hits().tobytes() == ora0["hits"].tobytes(), (levels, counters, with_run_off)
                     assert r.calls().tobytes() == ora0["calls"].tobytes() and r.otu().tobytes() == ora0["otu"].tobytes()
                     assert r.stats["lookup_ran_off"] == int(with_run_off), (levels, counters, r.stats["lookup_ran_off"])

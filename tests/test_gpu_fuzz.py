@@ -21,7 +21,7 @@ KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_
 @pytest.mark.parametrize("seed", [21, 22])
 def test_both_strategies_against_the_oracle(oracle, monkeypatch, seed):
     from kmergutsjava_amd import hotpath
-    n_part = n_index = 0
+    n_part = n_index = n_bidx = 0
     for w in workloads(25, seed):
         p = w["params"]
         ora = oracle.run(w["img"], w["raw"], w["off"], lookup_mode=1, **p)
@@ -40,12 +40,14 @@ def test_both_strategies_against_the_oracle(oracle, monkeypatch, seed):
                     assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s %s" % (seed, w["it"], mode, w["env"], w["env2"] if mode == "2" else ""))
                     assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
                     n_part += r.stats["partitioned"]
-                if mode == "2":
-                    # without KG_F_COUNTERS the second level looks the entries up in the table's home index (sub_index_kernel)
+                if mode != "0":
+                    # without KG_F_COUNTERS the entries are looked up in the table's home indexes: one level -> the byte index
+                    # in the L2 (bucket_index_kernel), two levels -> the 16-bit index in LDS (sub_index_kernel)
                     with tab.scan(w["raw"], w["off"], hotpath.Params(**p)) as r:
-                        assert_same_records(r, ora, "fuzz seed %d it %d home index %s %s" % (seed, w["it"], w["env"], w["env2"]))
+                        assert_same_records(r, ora, "fuzz seed %d it %d home index %s %s" % (seed, w["it"], w["env"], w["env2"] if mode == "2" else ""))
                         n_index += r.stats["part_levels"] == 3
-    assert n_part >= 30 and n_index >= 10
+                        n_bidx += r.stats["part_levels"] == 4
+    assert n_part >= 30 and n_index >= 10 and n_bidx >= 10
 
 
 def test_strategies_agree_on_random_workloads():

@@ -12,16 +12,38 @@ from helpers import assert_same_records, plant
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["direct", "partitioned", "partitioned2"])
+@pytest.fixture(autouse=True, params=["direct", "partitioned", "partitioned_tags", "partitioned2"])
 def strategy(request, monkeypatch):
-    """Every parity test runs with the three scan strategies: direct probing, partitioned probing (KG_PARTITION=1
-    forces the bucketed path even on tables small enough for the direct one) with the tags probed in the L2, and
-    with the second partition level (KG_PART_LEVELS=2: sub-scatter + tags probed in LDS; 2^9-slot sub-buckets so that
-    the small test tables have several per bucket)."""
+    """Every parity test runs with the scan strategies: direct probing; partitioned probing (KG_PARTITION=1 forces the
+    bucketed path even on tables small enough for the direct one) -- the byte home index probed in the L2 by scans without
+    KG_F_COUNTERS, the tags by scans with them; the same with the index switched off (KG_BIDX=0: tags for every scan); and
+    the second partition level (KG_PART_LEVELS=2: sub-scatter + tags probed in LDS; 2^9-slot sub-buckets so that the small
+    test tables have several per bucket).
+    Most workloads here scan with counters (they compare them with the oracle's), which the index path does not serve: under
+    "partitioned" every such scan is therefore REPEATED without counters -- the index path -- and its records, event bytes and
+    flags must be the ones of the scan the test goes on to compare with the oracle."""
     monkeypatch.setenv("KG_PARTITION", "0" if request.param == "direct" else "1")
     monkeypatch.setenv("KG_PART_LEVELS", "2" if request.param == "partitioned2" else "1")
     if request.param == "partitioned2":
         monkeypatch.setenv("KG_PART_SUBSHIFT", "9")
+    if request.param == "partitioned_tags":
+        monkeypatch.setenv("KG_BIDX", "0")
+    if request.param == "partitioned":
+        import dataclasses
+        from kmergutsjava_amd import hotpath
+        plain = hotpath.SignatureTable.scan
+
+        def scan_and_cross_check(self, seq, offsets, params=None, device_ptr=None):
+            r = plain(self, seq, offsets, params, device_ptr)
+            if params is not None and params.counters and r.stats["partitioned"] == 1:
+                with plain(self, seq, offsets, dataclasses.replace(params, counters=False), device_ptr) as ri:
+                    assert ri.stats["part_levels"] == 4, ri.stats
+                    for kind in ("hits", "calls", "otu", "hit_events", "container_tail_events", "container_hit_start", "container_call_start"):
+                        assert getattr(ri, kind)().tobytes() == getattr(r, kind)().tobytes(), "index path vs tag path: %s differ" % kind
+                    for k in ("n_hits", "n_calls", "lookup_ran_off", "fallback"):
+                        assert ri.stats[k] == r.stats[k], (k, ri.stats[k], r.stats[k])
+            return r
+        monkeypatch.setattr(hotpath.SignatureTable, "scan", scan_and_cross_check)
     return request.param
 
 

@@ -11,7 +11,7 @@ import csv,sys,json,glob,os
 out,tag=sys.argv[1],sys.argv[2]
 f=glob.glob(out+'/**/*kernel_stats.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
-keys=os.environ.get('KSTAT_KEYS','bucket_tag,part_scatter,sub_scatter,sub_probe,sub_index,verify_kernel,overflow_probe,hit_hist,group_scan,hit_partition_kernel<true>,hit_partition_kernel<false>,group_place,row_geo').split(',')
+keys=os.environ.get('KSTAT_KEYS','bucket_tag,bucket_index,part_scatter,sub_scatter,sub_probe,sub_index,verify_kernel,overflow_probe,hit_hist,group_scan,hit_partition_kernel<true>,hit_partition_kernel<false>,group_place,row_geo').split(',')
 d={}
 for r in rows:
     for k in keys:
