@@ -20,7 +20,7 @@
  * one is read at the start of each call, so a test can change them between calls):
  *   KG_PARTITION (0 direct / 1 partitioned whenever possible / 2 auto), KG_PART_LEVELS (1 / 2), KG_PART_SHIFT,
  *   KG_PART_SUBSHIFT, KG_PART_CHUNKS, KG_PART_MIN_CHUNK_BLOCKS, KG_PART_WGS, KG_PART_SLACK, KG_PART_CAP2,
- *   KG_PART_OVF_GROUPS, KG_PART_TAPER, KG_PROBE_GRID, KG_PROBE_GRAB, KG_PROBE2_GRID, KG_SUB_GRID, KG_SUB_RPI,
+ *   KG_PART_OVF_GROUPS, KG_PART_TAPER, KG_PROBE_GRID, KG_INDEX_GRID, KG_INDEX_R, KG_PROBE_GRAB, KG_PROBE2_GRID, KG_SUB_GRID, KG_SUB_RPI,
  *   KG_VERIFY_GRID, KG_LOWC_GRID, KG_OVF_GRID, KG_ORDER_GRID, KG_ORDER_STREAMS, KG_PLACE_STAGED, KG_QIDX, KG_BIDX, KG_SCAN_GRID,
  *   KG_SCAN_RPG, KG_STAGE_CHUNK, KG_AGG_PIECES, KG_AGG_BLOCK_SHIFT: geometry of the
  *   scan strategies (kmerguts_hip.hip, scan_impl); results never depend on them.  KG_DEBUG: one stderr line per attempt.

@@ -74,8 +74,23 @@ constexpr int kMaxBuckets = 1024;
 #ifndef KG_TAG_STRADDLE
 #define KG_TAG_STRADDLE 0
 #endif
+// 1: the verify pass fetches the record at the home slot whole with the first round of keys (kScanOn candidates): stage
+// 16.37 -> 16.20 ms (r04 c04)
+#ifndef KG_SCAN_FULL
+#define KG_SCAN_FULL 1
+#endif
+// 1: when a workgroup of the byte-index pass moves on to a new bucket it requests its slice of the bucket its XCD group takes
+// NEXT (coalesced 16-byte loads, results unused): the index lines are then in the L2 when the probes come, instead of being
+// fetched one probe -- and one HBM latency per wave iteration -- at a time
+#ifndef KG_INDEX_PF
+#define KG_INDEX_PF 0
+#endif
 constexpr uint32_t kStageFlush = KG_STAGE_FLUSH;     // candidate records per flush of a tag wave's staging buffer (<= 64)
 constexpr int kProbeN = KG_PROBE_N;                  // queries per lane per iteration of the bucket probe
+#ifndef KG_INDEX_N
+#define KG_INDEX_N KG_PROBE_N
+#endif
+constexpr int kIndexN = KG_INDEX_N;                  // the same for the byte-index pass (31 VGPRs at 4: room for more in flight)
 constexpr uint32_t kUChunk = 512;           // records per reservation of the unordered hit list
 
 constexpr uint64_t kEntInvalid = ~0ull;     // filler entry (padding of a 16-entry group)
@@ -788,15 +803,21 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
 //                              occupied run at its end (home >= tail_start: lookup_ran_off, KGJ:799-802)
 // No fingerprint, no 16-tag window, no undecided window: ~40 VALU per entry against ~126, and 36.7 M + 6 M candidates per Gbp
 // of the bench against 65 M.  Not used by KG_F_COUNTERS scans (slots_inspected needs the walk: bucket_tag_kernel<true>).
+// N entries per lane and iteration, taken from R regions of the bucket at a time (R divides N): a hand-out costs the
+// workgroup a ticket, two barriers and the HBM latency of its first entries -- ~5 us, whatever the region holds -- so the
+// short regions of small chunks (a 125 Mbp shard in two chunks: 500 entries per region) are handed out two or four at a time and
+// walked side by side, 256 * N / R slots of each per iteration: full lanes and half / a quarter of the hand-outs.
+template <int N, int R>
 __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
-    const uint8_t *__restrict__ bidx, uint32_t exact /* classes are quotients */, uint32_t tail_start,
-    const uint64_t *__restrict__ ent, const uint32_t *__restrict__ fill, uint32_t n_regions, uint32_t cap, uint32_t n_buckets,
-    uint32_t shift, uint32_t grab /* entry slots per hand-out, multiple of 256 * kProbeN */,
+    const uint8_t *__restrict__ bidx, uint64_t n_bidx /* its length in bytes */, uint32_t exact /* classes are quotients */, uint32_t tail_start,
+    const uint64_t *__restrict__ ent, const uint32_t *__restrict__ fill, uint32_t n_regions /* multiple of R */, uint32_t cap, uint32_t n_buckets,
+    uint32_t shift, uint32_t grab /* entry slots (of every region) per hand-out, multiple of 256 * N / R */,
     uint32_t *next_region /* ticket counter of group x at [32 * x], zeroed */,
     CandRec *__restrict__ cand, uint32_t *__restrict__ cand_used, unsigned long long *cand_cursor, uint64_t cand_cap,
     unsigned long long *ctr)
 {
-    constexpr int N = kProbeN;
+    static_assert(N % R == 0, "R must divide N");
+    constexpr int PER = N / R;                          // entries per lane, region and iteration
     __shared__ uint32_t s_region;
     __shared__ uint32_t s_lut[256];
     __shared__ __attribute__((aligned(16))) CandRec s_stage[4][kStageFlush + 64];      // per wave: < kStageFlush records waiting + <= 64 new ones
@@ -810,10 +831,13 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
 
     const uint32_t kGrab = grab;
     const uint32_t grabs_per_region = (cap + kGrab - 1) / kGrab;
-    const uint32_t n_grabs = n_regions * grabs_per_region;
+    const uint32_t n_grabs = (n_regions / R) * grabs_per_region;
     const uint32_t xg = blockIdx.x & 7u;
     const uint32_t n_tickets = xg < n_buckets ? ((n_buckets - xg + 7u) / 8u) * n_grabs : 0u;
     const uint32_t all_walk = exact ? 0u : kBidxInexact;
+#if KG_INDEX_PF
+    uint32_t last_b = ~0u;
+#endif
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) s_region = atomicAdd(&next_region[xg * 32u], 1u);
@@ -821,28 +845,53 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
         const uint32_t tk = s_region;
         if (tk >= n_tickets) break;                 // the group's buckets are exhausted
         const uint32_t b = xg + 8u * (tk / n_grabs), g = tk % n_grabs;
-        const uint32_t w = g / grabs_per_region, g0 = (g % grabs_per_region) * kGrab;
-        const uint32_t fraw = fill[(uint64_t)b * n_regions + w];
-        uint32_t n = cap;                               // until the fill has arrived
-        const uint64_t *src = ent + ((uint64_t)b * n_regions + w) * cap;
+        const uint32_t w = (g / grabs_per_region) * R, g0 = (g % grabs_per_region) * kGrab;
+#if KG_INDEX_PF
+        if (b != last_b) {
+            last_b = b;
+            const uint32_t nb = b + 8u * KG_INDEX_PF;
+            if (nb < n_buckets) {
+                const uint32_t gs = gridDim.x >> 3, rank = blockIdx.x >> 3;
+                const uint32_t per = (((1u << shift) + gs - 1u) / gs + 4095u) & ~4095u;        // bytes per workgroup, whole 4 KB pieces
+                for (uint32_t o = rank * per; o < min((rank + 1u) * per, 1u << shift); o += 4096u) {
+                    const uint64_t at = ((uint64_t)nb << shift) + o + threadIdx.x * 16u;
+                    if (at + 16u <= n_bidx) {
+                        const kg_u32x4 v = *reinterpret_cast<const kg_u32x4 *>(bidx + at);
+                        asm volatile("; prefetched index line" :: "v"(v));
+                    }
+                }
+            }
+        }
+#endif
+        // the regions' fills are requested together with their first batch of entries (slots below cap are mapped; what lies
+        // behind the fill is discarded below): one round trip less per hand-out
+        uint32_t fraw[R], n[R], nmax = cap;
+#pragma unroll
+        for (int r = 0; r < R; r++) { fraw[r] = fill[(uint64_t)b * n_regions + w + r]; n[r] = cap; }
+        const uint64_t *src = ent + ((uint64_t)b * n_regions + w) * cap;          // region r of the hand-out: src + r * cap
         const uint32_t smask = (1u << shift) - 1u, bbase = b << shift;
-        for (uint32_t c0 = g0; c0 < n && c0 < g0 + kGrab; c0 += 256u * N) {
-            const uint32_t bound = n;
+        for (uint32_t c0 = g0; c0 < nmax && c0 < g0 + kGrab; c0 += 256u * PER) {
             uint64_t ev[N];
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                const uint32_t i = c0 + (uint32_t)k * 256u + threadIdx.x;
-                ev[k] = i < bound ? __builtin_nontemporal_load(src + i) : kEntInvalid;
+                const int r = k / PER;
+                const uint32_t i = c0 + (uint32_t)(k % PER) * 256u + threadIdx.x;
+                ev[k] = i < n[r] ? __builtin_nontemporal_load(src + (uint64_t)r * cap + i) : kEntInvalid;
             }
             if (c0 == g0) {
-                uint32_t f = fraw;
-                asm volatile("; fill first used here" : "+s"(f));       // (keeps the scalar wait behind the entry loads)
-                n = min(f, cap);                                        // (bulk appends may have run past the region)
+                nmax = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    uint32_t f = fraw[r];
+                    asm volatile("; fill first used here" : "+s"(f));   // (keeps the scalar wait behind the entry loads)
+                    n[r] = min(f, cap);                                 // (bulk appends may have run past the region)
+                    nmax = max(nmax, n[r]);
+                }
             }
             uint32_t code[N], vmask = 0;
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                if (c0 + (uint32_t)k * 256u + threadIdx.x >= n) ev[k] = kEntInvalid;
+                if (c0 + (uint32_t)(k % PER) * 256u + threadIdx.x >= n[k / PER]) ev[k] = kEntInvalid;
                 code[k] = 0;
                 if (ev[k] != kEntInvalid) {
                     vmask |= 1u << k;
@@ -939,7 +988,23 @@ __global__ __launch_bounds__(256) void verify_kernel(
                 // carries it is the one the reference finds (KGJ:1003-1015)
                 // (three keys are requested together: a key sits 0.5 slots behind its home slot on average at load 0.5, and
                 //  the slowest lane of the wave sets the pace; records of neighbouring slots share their 128-byte line)
-                for (;;) {
+#if KG_SCAN_FULL
+                // the record AT the home slot whole (two out of three listed keys sit there: a key is 0.5 slots behind its
+                // home slot on average at load 0.5) and the keys of the two records behind it, all in flight together: one
+                // round trip instead of two (keys, then the payload) for most candidates
+                if (s < limit) {
+                    const uint64_t s1 = s + 1 < limit ? s + 1 : s, s2 = s + 2 < limit ? s + 2 : s;
+                    const Entry e0 = load_entry(tab, s);
+                    const uint2 k1 = *reinterpret_cast<const uint2 *>(tab.entries + s1 * 24);
+                    const uint2 k2 = *reinterpret_cast<const uint2 *>(tab.entries + s2 * 24);
+                    const uint32_t vlo = (uint32_t)val, vhi = (uint32_t)(val >> 32);
+                    if (e0.key == (int64_t)val) { found = true; e = e0; }
+                    else if (s + 1 < limit && k1.x == vlo && k1.y == vhi) { found = true; s += 1; e = load_entry(tab, s); }
+                    else if (s + 2 < limit && k2.x == vlo && k2.y == vhi) { found = true; s += 2; e = load_entry(tab, s); }
+                    else s += 3;
+                }
+#endif
+                while (!found) {
                     if (s >= limit) { s = limit; ran_off = true; break; }      // (only if the table changed under the index)
                     const uint64_t s1 = s + 1 < limit ? s + 1 : s, s2 = s + 2 < limit ? s + 2 : s;
                     const uint2 k0 = *reinterpret_cast<const uint2 *>(tab.entries + s * 24);

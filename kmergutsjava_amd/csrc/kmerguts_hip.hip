@@ -1023,6 +1023,15 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         // Round 2 (one tag wave per SIMD beside the scatter pass): 4 per CU 20.4 ms, 8 per CU 20.8 (profiles/r02_pipeline.md);
         // round 3 (two): 4 per CU 19.78 ms, 8 per CU 19.56, bench.py 20.5 -> 20.25 ms per step (profiles/r03_experiments.md).
         const uint32_t probe_grid = env_u32("KG_PROBE_GRID", 256u * 8u) & ~7u;
+        // the byte-index pass: four workgroups per CU -- at 32 VGPRs they are the four waves per SIMD that fit beside a scatter
+        // workgroup (4 x 96 + 4 x 32 = 512); with eight queued the stage is 0.4 ms slower (16.37 against 15.93 ms, r04 c04)
+        const uint32_t index_grid = env_u32("KG_INDEX_GRID", 256u * 4u) & ~7u;
+        // ... and the regions it takes per hand-out: regions expected to hold fewer than ~640 / ~320 entries (about 0.7 of the
+        // mean the capacity was computed from is valid DNA) are handed out two / four at a time (bucket_index_kernel)
+        uint32_t index_r = env_u32("KG_INDEX_R", 0u);
+        if (index_r == 0) index_r = mean * 0.7 >= 640.0 ? 1u : mean * 0.7 >= 320.0 ? 2u : 4u;
+        if (index_r != 1 && index_r != 2) index_r = 4;
+        while (index_r > 1 && (n_wg % index_r != 0 || kg::kIndexN % index_r != 0)) index_r /= 2;
         // verify workgroups: two per CU.  With eight (until round 3) the pass alone is 15 % faster, but its workgroups take all the
         // registers an ending tag pass frees, and the next tag pass -- the critical chain -- starts behind them: stage 18.3 ->
         // 18.15 ms, 125 Mbp shard 3.18 -> 3.10 (profiles/r03_experiments.md)
@@ -1034,7 +1043,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         const uint32_t lowc_grid = env_u32("KG_LOWC_GRID", 256u), ovf_grid = env_u32("KG_OVF_GRID", 256u);
         // per-chunk lists: hits (unordered) and candidates = fingerprint matches (hits + ~0.4 % of the probes) + the
         // ~2 % of the probes whose first tag window decides nothing
-        const uint64_t list_slack = (uint64_t)(std::max(probe_grid, verify_grid) + 64) * 4 * kg::kUChunk + 4096;
+        const uint64_t list_slack = (uint64_t)(std::max(std::max(probe_grid, index_grid), verify_grid) + 64) * 4 * kg::kUChunk + 4096;
         uint64_t ucap = ((uint64_t)((double)windows * t->stage_ratio * max_frac) + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         uint64_t ccap = ((uint64_t)((double)windows * (t->stage_ratio * 1.25 + 0.03) * max_frac) + list_slack + kg::kUChunk - 1) /
                         kg::kUChunk * kg::kUChunk;
@@ -1050,7 +1059,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             ~ListGuard() { for (void **q : slot) if (*q) { sc.adopt(*q); *q = nullptr; } }
         } list_guard{sc, {(void **)&d_ulist, (void **)&d_cused, (void **)&d_cand, (void **)&d_candused, (void **)&d_sortA, (void **)&d_sortB}};
         bool too_skewed = false;
-        const uint32_t grab_unit = 256u * kg::kProbeN;
+        const uint32_t grab_unit = 256u * (uint32_t)std::max(kg::kProbeN, kg::kIndexN);      // (powers of two: the larger is a multiple of the other)
         const uint32_t probe_grab = (std::max(env_u32("KG_PROBE_GRAB", cap), grab_unit) + grab_unit - 1) / grab_unit * grab_unit;
         uint64_t h_tot[6] = {0, 0, 0, 0, 0, 0};
         HIP_TRY(hipEventRecord(t->ev[1], t->stream));
@@ -1142,10 +1151,15 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                     else if (counters) hipLaunchKernelGGL((kg::sub_probe_kernel<true>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
                     else hipLaunchKernelGGL((kg::sub_probe_kernel<false>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
 #undef KG_TAG2_ARGS
-                } else if (use_bidx)
-                    hipLaunchKernelGGL(kg::bucket_index_kernel, dim3(probe_grid), dim3(256), 0, s2, t->d_bidx, t->bidx_exact ? 1u : 0u,
-                                       (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent_c, fill_c, n_wg, cap, part_buckets,
-                                       part_shift, probe_grab, next_c, cand_c, candused_c, ccur_c, ccap, d_ctr);
+                } else if (use_bidx) {
+#define KG_INDEX_ARGS t->d_bidx, (uint64_t)(t->limit + kg::kTagPad), t->bidx_exact ? 1u : 0u, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent_c, fill_c, n_wg, cap, \
+                      part_buckets, part_shift, probe_grab, next_c, cand_c, candused_c, ccur_c, ccap, d_ctr
+                    // regions per hand-out by their expected fill (an iteration covers 256 * N / R entry slots of each)
+                    if (index_r <= 1) hipLaunchKernelGGL((kg::bucket_index_kernel<kg::kIndexN, 1>), dim3(index_grid), dim3(256), 0, s2, KG_INDEX_ARGS);
+                    else if (index_r == 2) hipLaunchKernelGGL((kg::bucket_index_kernel<kg::kIndexN, 2>), dim3(index_grid), dim3(256), 0, s2, KG_INDEX_ARGS);
+                    else hipLaunchKernelGGL((kg::bucket_index_kernel<kg::kIndexN, 4>), dim3(index_grid), dim3(256), 0, s2, KG_INDEX_ARGS);
+#undef KG_INDEX_ARGS
+                }
                 else if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
                 else hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
                 HIP_TRY(hipEventRecord(t->pev[2 * c + 1], s2));
