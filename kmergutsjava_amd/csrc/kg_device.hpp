@@ -314,15 +314,27 @@ __device__ __forceinline__ uint32_t lds_bytes4(const uint8_t *base, uint32_t at)
 #endif
 }
 
+// the 48-bit product of two 24-bit numbers, both halves at full rate.  (Inline asm: hipcc's hazard recognizer does not see
+// what an asm statement reads, so the operands must not come straight out of a v_dot4 / MFMA / transcendental -- those need
+// wait states before a dependent VALU; round 4 learnt it from an asm'd v_mad_u32_u24 behind two v_dot4: wrong k-mer codes.)
+__device__ __forceinline__ uint64_t mul24_wide(uint32_t a, uint32_t b)
+{
+    uint32_t lo, hi;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    return ((uint64_t)hi << 32) | lo;
+}
 // bytes (c0, c1, c2, c3) of w, c0 lowest -> c0 * 8000 + c1 * 400 + c2 * 20 + c3
 __device__ __forceinline__ uint32_t half_up(uint32_t w)
 {
-    return __umul24(dot4(w, 0x00000114u), 400u) + dot4(w, 0x01140000u);
+    // (the second dot accumulates onto the first one's product: written as product + dot, hipcc emits a quarter-rate
+    //  v_mad_u64_u32 for the half that feeds split_fast's 24-bit multiplies -- one per window row in the scatter pass)
+    return dot4(w, 0x01140000u, __umul24(dot4(w, 0x00000114u), 400u));
 }
 // the same with c3 the most significant: c3 * 8000 + c2 * 400 + c1 * 20 + c0
 __device__ __forceinline__ uint32_t half_down(uint32_t w)
 {
-    return __umul24(dot4(w, 0x14010000u), 400u) + dot4(w, 0x00001401u);
+    return dot4(w, 0x00001401u, __umul24(dot4(w, 0x14010000u), 400u));
 }
 
 // Lookup tables shared by the waves of a workgroup (built once per workgroup by encode_init).

@@ -69,22 +69,13 @@ constexpr int kMaxBuckets = 1024;
 #ifndef KG_SCATTER_RG
 #define KG_SCATTER_RG 6
 #endif
-// 1: the tag pass reads its 16 tags AT the home slot even when they straddle a 128-byte line (both lines are L2-resident
-// on this path: one more L2 request in 12 % of the probes, but the window always covers 16 slots: fewer undecided windows).
-#ifndef KG_TAG_STRADDLE
-#define KG_TAG_STRADDLE 0
-#endif
+
 // 1: the verify pass fetches the record at the home slot whole with the first round of keys (kScanOn candidates): stage
 // 16.37 -> 16.20 ms (r04 c04)
 #ifndef KG_SCAN_FULL
 #define KG_SCAN_FULL 1
 #endif
-// 1: when a workgroup of the byte-index pass moves on to a new bucket it requests its slice of the bucket its XCD group takes
-// NEXT (coalesced 16-byte loads, results unused): the index lines are then in the L2 when the probes come, instead of being
-// fetched one probe -- and one HBM latency per wave iteration -- at a time
-#ifndef KG_INDEX_PF
-#define KG_INDEX_PF 0
-#endif
+
 constexpr uint32_t kStageFlush = KG_STAGE_FLUSH;     // candidate records per flush of a tag wave's staging buffer (<= 64)
 constexpr int kProbeN = KG_PROBE_N;                  // queries per lane per iteration of the bucket probe
 #ifndef KG_INDEX_N
@@ -153,7 +144,10 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
     typedef typename WaveLds<AA>::type Enc;
     constexpr size_t enc_bytes = (sizeof(Enc) + 15) & ~(size_t)15;
     extern __shared__ __attribute__((aligned(16))) unsigned char part_lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave number through readfirstlane: the compiler then knows that the block number, the block descriptor and
+    //  everything computed from them -- row indices, the '-' strand's % 3, window keys' row part -- are wave-uniform and
+    //  keeps them in scalar registers: 7 quarter-rate multiplies and ~50 VALU per block were per-lane copies of them)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     Enc &l = *reinterpret_cast<Enc *>(part_lds + enc_bytes * wave);
     typedef typename WaveLds<AA>::tables Tables;
     constexpr size_t tab_bytes = (sizeof(Tables) + 15) & ~(size_t)15;
@@ -333,7 +327,9 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
                     done &= done - 1;
                     const uint32_t rel = wrel[b];
                     if (rel + kGroup <= cap) {
-                        dst_off = ((uint64_t)b * n_wg + w) * cap + rel;
+                        // (b * n_wg + w < 2^18 and cap < 2^24: 24-bit multiplies, full rate; the plain 64-bit expression
+                        //  compiles to three quarter-rate v_mad_u64_u32 per flush pass)
+                        dst_off = mul24_wide(b * n_wg + w, cap) + rel;
                         wrel[b] = rel + kGroup;
                     } else {
                         to_ovf = true;
@@ -714,12 +710,7 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
                 id[k] = (uint32_t)(e >> 32);
                 const uint32_t home = bbase | (low[k] & smask);
                 fp[k] = tag_qs(low[k] >> shift, home);
-#if KG_TAG_STRADDLE
-                skip[k] = 0;
-                const uint32_t cur = home;                                       // (may straddle two L2-resident lines)
-#else
                 const uint32_t cur = (uint32_t)probe_window(home, &skip[k]);     // home - skip (skip != 0: the window straddles a line)
-#endif
                 if ((vmask >> k) & 1u) tg[k] = load_tags(tags + cur);
             }
             // a window that holds neither an empty slot nor the fingerprint (2 % of the probes: straddling windows,
@@ -809,7 +800,7 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
 // walked side by side, 256 * N / R slots of each per iteration: full lanes and half / a quarter of the hand-outs.
 template <int N, int R>
 __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
-    const uint8_t *__restrict__ bidx, uint64_t n_bidx /* its length in bytes */, uint32_t exact /* classes are quotients */, uint32_t tail_start,
+    const uint8_t *__restrict__ bidx, uint32_t exact /* classes are quotients */, uint32_t tail_start,
     const uint64_t *__restrict__ ent, const uint32_t *__restrict__ fill, uint32_t n_regions /* multiple of R */, uint32_t cap, uint32_t n_buckets,
     uint32_t shift, uint32_t grab /* entry slots (of every region) per hand-out, multiple of 256 * N / R */,
     uint32_t *next_region /* ticket counter of group x at [32 * x], zeroed */,
@@ -835,9 +826,6 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
     const uint32_t xg = blockIdx.x & 7u;
     const uint32_t n_tickets = xg < n_buckets ? ((n_buckets - xg + 7u) / 8u) * n_grabs : 0u;
     const uint32_t all_walk = exact ? 0u : kBidxInexact;
-#if KG_INDEX_PF
-    uint32_t last_b = ~0u;
-#endif
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) s_region = atomicAdd(&next_region[xg * 32u], 1u);
@@ -846,23 +834,6 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
         if (tk >= n_tickets) break;                 // the group's buckets are exhausted
         const uint32_t b = xg + 8u * (tk / n_grabs), g = tk % n_grabs;
         const uint32_t w = (g / grabs_per_region) * R, g0 = (g % grabs_per_region) * kGrab;
-#if KG_INDEX_PF
-        if (b != last_b) {
-            last_b = b;
-            const uint32_t nb = b + 8u * KG_INDEX_PF;
-            if (nb < n_buckets) {
-                const uint32_t gs = gridDim.x >> 3, rank = blockIdx.x >> 3;
-                const uint32_t per = (((1u << shift) + gs - 1u) / gs + 4095u) & ~4095u;        // bytes per workgroup, whole 4 KB pieces
-                for (uint32_t o = rank * per; o < min((rank + 1u) * per, 1u << shift); o += 4096u) {
-                    const uint64_t at = ((uint64_t)nb << shift) + o + threadIdx.x * 16u;
-                    if (at + 16u <= n_bidx) {
-                        const kg_u32x4 v = *reinterpret_cast<const kg_u32x4 *>(bidx + at);
-                        asm volatile("; prefetched index line" :: "v"(v));
-                    }
-                }
-            }
-        }
-#endif
         // the regions' fills are requested together with their first batch of entries (slots below cap are mapped; what lies
         // behind the fill is discarded below): one round trip less per hand-out
         uint32_t fraw[R], n[R], nmax = cap;

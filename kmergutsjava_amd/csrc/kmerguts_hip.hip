@@ -880,7 +880,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         part_buckets = (uint32_t)((t->limit + (1ull << shift) - 1) >> shift);
     }
     bool part_done = false;
-    if (use_part) {
+    if (use_part) do {
         constexpr uint32_t WIN = AA ? 64u : 384u;                                    // windows per block
         constexpr uint32_t kMaxChunks = 8;
         const uint32_t per_iter = kg::kScatterWaves;
@@ -892,7 +892,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         uint32_t want = env_u32("KG_PART_CHUNKS", 4u);
         if (want < 1) want = 1;
         if (want > kMaxChunks) want = kMaxChunks;
-        const uint64_t min_chunk = std::max(1u, env_u32("KG_PART_MIN_CHUNK_BLOCKS", 1u << 20));   // ~200 Mbp; tests lower it
+        // at least ~115 Mbp per chunk (tests lower it): a pass has costs that do not shrink with the chunk -- a 125 Mbp shard is
+        // slower in two chunks (3.00 ms against 2.95, r04 c07), 250 Mbp faster (4.99 against 5.25)
+        const uint64_t min_chunk = std::max(1u, env_u32("KG_PART_MIN_CHUNK_BLOCKS", 600000u));
         while (want > 1 && nblocks / want < min_chunk) want--;
         std::vector<uint64_t> clo;                                                    // chunk c = blocks [clo[c], clo[c+1])
         std::vector<int64_t> cseq;                                                    //         = sequences [cseq[c], cseq[c+1])
@@ -928,7 +930,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         const uint64_t blocks_per_wg = ((chunk_blocks + (uint64_t)n_wg * per_iter - 1) / ((uint64_t)n_wg * per_iter)) * per_iter;
         // region capacity: the mean if every window were valid and hashed uniformly, plus 6 sigma, in 16-entry groups
         const double mean = (double)blocks_per_wg * WIN / (double)part_buckets * (env_u32("KG_PART_SLACK", 100u) / 100.0);
-        const uint32_t cap = (uint32_t)(((uint64_t)(mean + 6.0 * std::sqrt(mean) + 32.0) + 15) / 16 * 16);
+        const uint64_t cap64 = ((uint64_t)(mean + 6.0 * std::sqrt(mean) + 32.0) + 15) / 16 * 16;
+        // the scatter pass's address arithmetic is in 24-bit multiplies (region number x capacity): geometries beyond that
+        // (one bucket and millions of blocks per scatter workgroup; not reachable with the default knobs) take the direct path
+        if (cap64 >= (1ull << 24) || (uint64_t)part_buckets * n_wg >= (1ull << 24)) break;
+        const uint32_t cap = (uint32_t)cap64;
         const uint64_t n_regions_total = (uint64_t)part_buckets * n_wg;               // per chunk
         // overflow list of one chunk (groups): an eighth of the regions' capacity (low-complexity sequence: 3 % of the
         // bases in homopolymer runs overflow ~5 % of the entries; beyond the list the scan falls back to direct probing)
@@ -1117,17 +1123,25 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
                                    d_blocks, lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
                                    cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, ovfc_c + 1, d_lowc + lo, d_ctr);
+                hipStream_t s2 = t->stream2, s3 = t->stream3;
+                // KG_LOWC_STREAM=1: the (usually idle) low-complexity kernel runs behind its chunk's scatter pass on the scatter
+                // stream -- where the CUs have just been vacated -- instead of in front of the chunk's tag pass on the tag stream
+                const bool lowc_on_scatter = env_u32("KG_LOWC_STREAM", 0u) != 0;
+                if (lowc_on_scatter)
+                    hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(lowc_grid), dim3(64 * kg::kLowcWaves), 0, t->stream, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
+                                       t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
+                                       ovf_bucket_c, ovf_ent_c, d_ctr);
                 HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
                 HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
-                hipStream_t s2 = t->stream2, s3 = t->stream3;
                 // the low-complexity blocks the scatter pass set aside (usually none: every workgroup reads the count and
                 // leaves).  In front of the chunk's tag pass, not behind its scatter pass, and in one-wave workgroups whose
                 // 4.9 KB of LDS fit beside a resident scatter workgroup (153 KB of a CU's 160): with four-wave workgroups
                 // (15.8 KB) the kernel -- and the tag pass behind it -- waited for the NEXT chunk's scatter pass to leave
                 // the CUs (profiles/r02_pipeline.md).
-                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(lowc_grid), dim3(64 * kg::kLowcWaves), 0, s2, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
-                                   t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
-                                   ovf_bucket_c, ovf_ent_c, d_ctr);
+                if (!lowc_on_scatter)
+                    hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(lowc_grid), dim3(64 * kg::kLowcWaves), 0, s2, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
+                                       t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
+                                       ovf_bucket_c, ovf_ent_c, d_ctr);
 #define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
                     candused_c, ccur_c, ccap, d_ctr
 #define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_ctr
@@ -1152,7 +1166,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                     else hipLaunchKernelGGL((kg::sub_probe_kernel<false>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
 #undef KG_TAG2_ARGS
                 } else if (use_bidx) {
-#define KG_INDEX_ARGS t->d_bidx, (uint64_t)(t->limit + kg::kTagPad), t->bidx_exact ? 1u : 0u, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent_c, fill_c, n_wg, cap, \
+#define KG_INDEX_ARGS t->d_bidx, t->bidx_exact ? 1u : 0u, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent_c, fill_c, n_wg, cap, \
                       part_buckets, part_shift, probe_grab, next_c, cand_c, candused_c, ccur_c, ccap, d_ctr
                     // regions per hand-out by their expected fill (an iteration covers 256 * N / R entry slots of each)
                     if (index_r <= 1) hipLaunchKernelGGL((kg::bucket_index_kernel<kg::kIndexN, 1>), dim3(index_grid), dim3(256), 0, s2, KG_INDEX_ARGS);
@@ -1306,7 +1320,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             st.part_chunks = (int32_t)n_chunks_p; st.part_buckets = (int32_t)part_buckets; st.part_shift = (int32_t)part_shift;
             st.part_levels = (int32_t)(levels == 2 && use_qidx ? 3 : use_bidx ? 4 : levels);
         }
-    }
+    } while (0);
     if (!part_done) {
         st.scan_launches = 0;
         if (!seq_uploaded) { if ((rc = upload(offsets[0], offsets[n_seqs]))) return rc; seq_uploaded = true; }

@@ -81,7 +81,7 @@ def plant(seq_bytes: bytes, off, keys, every=40, dna=True, start=10):
     return bytes(s)
 
 
-def chunk_seq_ranges(off, want=4, dna=True, min_chunk_blocks=1 << 20):
+def chunk_seq_ranges(off, want=4, dna=True, min_chunk_blocks=600000):
     """The sequence ranges [a, b) of the chunks the partitioned scan cuts a batch into (kmerguts_hip.hip, scan_impl:
     chunk c starts at the first sequence whose first window block is >= nblocks * c / want; fewer chunks while a
     chunk would hold fewer than min_chunk_blocks blocks).  A DNA block is 192 forward positions, a protein block
