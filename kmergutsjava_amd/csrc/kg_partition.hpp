@@ -798,9 +798,11 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
 // workgroup a ticket, two barriers and the HBM latency of its first entries -- ~5 us, whatever the region holds -- so the
 // short regions of small chunks (a 125 Mbp shard in two chunks: 500 entries per region) are handed out two or four at a time and
 // walked side by side, 256 * N / R slots of each per iteration: full lanes and half / a quarter of the hand-outs.
-template <int N, int R>
+// EXACT: the table's quotients are all below 19, a class IS the quotient (no q % 19: two quarter-rate multiplies per entry,
+// which the compiler otherwise computes for every entry and then selects away -- half of the pass's VALU time, r04 ISA).
+template <int N, int R, bool EXACT>
 __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
-    const uint8_t *__restrict__ bidx, uint32_t exact /* classes are quotients */, uint32_t tail_start,
+    const uint8_t *__restrict__ bidx, uint32_t tail_start,
     const uint64_t *__restrict__ ent, const uint32_t *__restrict__ fill, uint32_t n_regions /* multiple of R */, uint32_t cap, uint32_t n_buckets,
     uint32_t shift, uint32_t grab /* entry slots (of every region) per hand-out, multiple of 256 * N / R */,
     uint32_t *next_region /* ticket counter of group x at [32 * x], zeroed */,
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
     const uint32_t n_grabs = (n_regions / R) * grabs_per_region;
     const uint32_t xg = blockIdx.x & 7u;
     const uint32_t n_tickets = xg < n_buckets ? ((n_buckets - xg + 7u) / 8u) * n_grabs : 0u;
-    const uint32_t all_walk = exact ? 0u : kBidxInexact;
+    constexpr uint32_t all_walk = EXACT ? 0u : kBidxInexact;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) s_region = atomicAdd(&next_region[xg * 32u], 1u);
@@ -869,16 +871,18 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
                     code[k] = bidx[bbase | ((uint32_t)ev[k] & smask)];      // the home slot's byte, out of the L2
                 }
             }
-            uint32_t candm = 0, walkm = 0;
+            // branch-free: the N decodes' LDS reads are in flight together; an entry slot without an entry has code 0 = nothing listed
+            uint32_t candm = 0, walkm = 0, wd[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) wd[k] = s_lut[code[k]];
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 const uint32_t q = (uint32_t)ev[k] >> shift;
-                const uint32_t wd = s_lut[code[k]] | all_walk;
-                const uint32_t c = exact ? q : q % kBidxClasses;
-                if ((vmask >> k) & 1u) {
-                    if ((wd >> c) & 1u) { candm |= 1u << k; if (wd & kBidxInexact) walkm |= 1u << k; }
-                    else if ((bbase | ((uint32_t)ev[k] & smask)) >= tail_start) ran_off = true;
-                }
+                const uint32_t c = EXACT ? q : q % kBidxClasses;
+                const uint32_t listed = (wd[k] >> c) & 1u;
+                candm |= listed << k;
+                walkm |= (listed & ((wd[k] | all_walk) >> 31)) << k;
+                ran_off = ran_off || (((vmask >> k) & 1u) && !listed && (bbase | ((uint32_t)ev[k] & smask)) >= tail_start);
             }
 #pragma unroll
             for (int k = 0; k < N; k++) {

@@ -1166,12 +1166,14 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                     else hipLaunchKernelGGL((kg::sub_probe_kernel<false>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
 #undef KG_TAG2_ARGS
                 } else if (use_bidx) {
-#define KG_INDEX_ARGS t->d_bidx, t->bidx_exact ? 1u : 0u, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent_c, fill_c, n_wg, cap, \
+#define KG_INDEX_ARGS t->d_bidx, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent_c, fill_c, n_wg, cap, \
                       part_buckets, part_shift, probe_grab, next_c, cand_c, candused_c, ccur_c, ccap, d_ctr
-                    // regions per hand-out by their expected fill (an iteration covers 256 * N / R entry slots of each)
-                    if (index_r <= 1) hipLaunchKernelGGL((kg::bucket_index_kernel<kg::kIndexN, 1>), dim3(index_grid), dim3(256), 0, s2, KG_INDEX_ARGS);
-                    else if (index_r == 2) hipLaunchKernelGGL((kg::bucket_index_kernel<kg::kIndexN, 2>), dim3(index_grid), dim3(256), 0, s2, KG_INDEX_ARGS);
-                    else hipLaunchKernelGGL((kg::bucket_index_kernel<kg::kIndexN, 4>), dim3(index_grid), dim3(256), 0, s2, KG_INDEX_ARGS);
+#define KG_INDEX_LAUNCH(R, X) hipLaunchKernelGGL((kg::bucket_index_kernel<kg::kIndexN, R, X>), dim3(index_grid), dim3(256), 0, s2, KG_INDEX_ARGS)
+                    // regions per hand-out by their expected fill (an iteration covers 256 * N / R entry slots of each); the
+                    // kernel for tables whose classes are their quotients has no q % 19
+                    if (t->bidx_exact) { if (index_r <= 1) KG_INDEX_LAUNCH(1, true); else if (index_r == 2) KG_INDEX_LAUNCH(2, true); else KG_INDEX_LAUNCH(4, true); }
+                    else { if (index_r <= 1) KG_INDEX_LAUNCH(1, false); else if (index_r == 2) KG_INDEX_LAUNCH(2, false); else KG_INDEX_LAUNCH(4, false); }
+#undef KG_INDEX_LAUNCH
 #undef KG_INDEX_ARGS
                 }
                 else if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
