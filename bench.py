@@ -320,10 +320,10 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "bound_note": ("priced against HBM as SURVEY 8d prescribes; the partitioned scan moves fewer HBM "
                                         "bytes than the algorithmic count and its passes are bound by VALU/LDS issue "
-                                        "(scatter), L2/LDS tag reads (tag pass) and random HBM lines (verification): "
+                                        "(scatter), the L2's line-gather rate (index pass: one byte of the table's home index per query) and random HBM lines (verification): "
                                         "DESIGN.md section 6") if partitioned else
                                        "direct probing: every 16-byte probe moves a 128-byte line from HBM",
-                         "kernel": ("scan stage = kg::part_scatter_kernel || kg::bucket_tag_kernel || kg::verify_kernel + "
+                         "kernel": ("scan stage = kg::part_scatter_kernel || kg::bucket_index_kernel || kg::verify_kernel + "
                                     "ordered placement (kg::hit_partition_kernel x 2, kg::group_place_kernel): chunks of whole "
                                     "contigs on three streams" if partitioned else "kg::scan_kernel<false,false,3>"),
                          "kernel_ms": ms_scan,

@@ -15,7 +15,8 @@ timeout -k 10 600 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err || 
 cat $OUT/bench.json | cut -c1-300
 
 echo "== rocprofv3 --kernel-trace --stats (same command)"
-timeout -k 10 700 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py \
+# (--no-extra-configs: configs 2 and 5 launch the same kernels on smaller batches and would drag their averages down)
+timeout -k 10 700 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-extra-configs \
     > $OUT/bench_traced.json 2> $OUT/bench_traced.err || echo "trace rc=$?"
 
 echo "== counters available"
@@ -24,7 +25,7 @@ rocprofv3 -L 2>/dev/null | grep -i -E "FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ|TCC_E
 pmc() {   # name, counters...
     local name=$1; shift
     timeout -k 10 600 rocprofv3 --pmc "$@" --kernel-include-regex "kg::" --output-format csv -d $OUT/pmc_$name -- \
-        python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err || echo "pmc $name rc=$?"
+        python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err || echo "pmc $name rc=$?"
 }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE

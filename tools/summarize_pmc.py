@@ -16,7 +16,7 @@ f, w = agg(R + "/pmc_fetch/runc/*_counter_collection.csv"), agg(R + "/pmc_write/
 q, h = agg(R + "/pmc_rdreq/runc/*_counter_collection.csv"), agg(R + "/pmc_hit/runc/*_counter_collection.csv")
 bench = json.load(open(R + "/pmc_fetch.json"))
 strategy = bench["roofline"]["strategy"]
-scan_kernels = [k for k in f if any(x in k for x in (("part_scatter", "bucket_tag", "sub_scatter", "sub_probe", "sub_index", "verify_kernel", "overflow_probe", "row_geo", "hit_hist", "group_scan", "hit_partition", "group_place", "lowc_blocks", "chunk_base") if strategy == "partitioned" else ("scan_kernel<false, false",)))]
+scan_kernels = [k for k in f if any(x in k for x in (("part_scatter", "bucket_tag", "bucket_index", "sub_scatter", "sub_probe", "sub_index", "verify_kernel", "overflow_probe", "row_geo", "hit_hist", "group_scan", "hit_partition", "group_place", "lowc_blocks", "chunk_base") if strategy == "partitioned" else ("scan_kernel<false, false",)))]
 per_kernel = {}
 tot_fetch = tot_write = 0.0
 steps = 1      # the PMC runs use --steps 1 --warmup 0 plus the counters launch: take the launches of the LAST scan
@@ -31,11 +31,21 @@ for k in sorted(f):
                      "TCC_MISS_per_launch": sum(h[k]["TCC_MISS_sum"]) / max(1, len(h[k]["TCC_MISS_sum"]))}
 # one scan = all launches of the scan-stage kernels in one bench step; the PMC bench run makes 2 scans (counters + 1 timed)
 scans = 2
+# (round 4) the counters scan probes the tags (bucket_tag_kernel<true> + the <.., true> verify kernels), the timed scan the byte
+# home index (bucket_index_kernel + the <.., false> verify kernels): the timed scan = its own kernels whole + half of the
+# launches of the kernels both scans share
+COUNTERS_ONLY = ("bucket_tag_kernel<true>", "verify_kernel<false, true>", "verify_kernel<true, true>", "overflow_probe_kernel<false, true>",
+                 "overflow_probe_kernel<true, true>")
+TIMED_ONLY = ("bucket_index_kernel", "bucket_tag_kernel<false>", "verify_kernel<false, false>", "verify_kernel<true, false>",
+              "overflow_probe_kernel<false, false>", "overflow_probe_kernel<true, false>")
 for k in scan_kernels:
     if "true>" in k and strategy == "direct":
         continue
-    tot_fetch += sum(f[k]["FETCH_SIZE"]) / scans * (2 if (strategy == "direct" and len(f[k]["FETCH_SIZE"]) == 1) else 1)
-    tot_write += sum(w[k]["WRITE_SIZE"]) / scans * (2 if (strategy == "direct" and len(w[k]["WRITE_SIZE"]) == 1) else 1)
+    if any(x in k for x in COUNTERS_ONLY):
+        continue
+    share = 1 if any(x in k for x in TIMED_ONLY) else scans
+    tot_fetch += sum(f[k]["FETCH_SIZE"]) / share * (2 if (strategy == "direct" and len(f[k]["FETCH_SIZE"]) == 1) else 1)
+    tot_write += sum(w[k]["WRITE_SIZE"]) / share * (2 if (strategy == "direct" and len(w[k]["WRITE_SIZE"]) == 1) else 1)
 out = {"round": rnd, "total_bp": bench["config"].get("total_bp_rank0", bench["config"].get("total_bp_per_gpu")),
        "num_sigs": bench["config"]["num_sigs"], "strategy": strategy,
        "scan_stage_kernels": scan_kernels, "FETCH_SIZE_KB_per_scan": tot_fetch, "WRITE_SIZE_KB_per_scan": tot_write,
