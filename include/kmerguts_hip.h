@@ -18,11 +18,11 @@
  *
  * Environment variables read by kg_scan* (tuning and test hooks, none needed in production; every
  * one is read at the start of each call, so a test can change them between calls):
- *   KG_PARTITION (0 direct / 1 partitioned whenever possible / 2 auto), KG_PART_LEVELS (1 / 2), KG_PART_SHIFT,
- *   KG_PART_SUBSHIFT, KG_PART_CHUNKS, KG_PART_MIN_CHUNK_BLOCKS, KG_PART_WGS, KG_PART_SLACK, KG_PART_CAP2,
- *   KG_PART_OVF_GROUPS, KG_PART_TAPER, KG_PROBE_GRID, KG_INDEX_GRID, KG_INDEX_R, KG_PROBE_GRAB, KG_PROBE2_GRID, KG_SUB_GRID, KG_SUB_RPI,
- *   KG_VERIFY_GRID, KG_LOWC_GRID, KG_OVF_GRID, KG_ORDER_GRID, KG_ORDER_STREAMS, KG_PLACE_STAGED, KG_QIDX, KG_BIDX, KG_SCAN_GRID,
- *   KG_SCAN_RPG, KG_STAGE_CHUNK, KG_AGG_PIECES, KG_AGG_BLOCK_SHIFT: geometry of the
+ *   KG_PARTITION (0 direct / 1 partitioned whenever possible / 2 auto), KG_BIDX (0: probe the tags, not the byte home index),
+ *   KG_PART_SHIFT, KG_PART_CHUNKS, KG_PART_MIN_CHUNK_BLOCKS, KG_PART_WGS, KG_PART_SLACK, KG_PART_OVF_GROUPS, KG_PART_TAPER,
+ *   KG_PROBE_GRID, KG_INDEX_GRID, KG_INDEX_R, KG_PROBE_GRAB, KG_VERIFY_GRID, KG_LOWC_GRID, KG_OVF_GRID,
+ *   KG_ORDER_GRID, KG_ORDER_STREAMS, KG_PLACE_STAGED, KG_SCAN_GRID, KG_SCAN_RPG, KG_STAGE_CHUNK, KG_AGG_PIECES, KG_AGG_BLOCK_SHIFT:
+ *   geometry of the
  *   scan strategies (kmerguts_hip.hip, scan_impl); results never depend on them.  KG_DEBUG: one stderr line per attempt.
  *   TEST HOOKS (used by tests/ only; inert unless the process set KG_ENABLE_TEST_HOOKS=1 before its FIRST kg_scan* -- that
  *   one is read once, so a stray KG_TEST_* variable in a server's environment does nothing): KG_TEST_TINY_LISTS=1 starts the hit / candidate lists at one chunk, so that the
@@ -138,11 +138,9 @@ typedef struct kg_stats {
                                  /* the records are the same either way (EOF == not found)                           */
     int32_t agg_pieces;          /* pieces beyond the first that long containers were cut into for gatherHits (cuts  */
                                  /* at gaps > maxGap, where the reference's list restarts anyway: KGJ:477-484)       */
-    int32_t part_levels;         /* partitioned only: 1 = tags probed in the L2 (bucket_tag_kernel), 2 = entries cut once more  */
-                                 /* by sub-bucket and tags probed in LDS (kg_partition2.hpp), 3 = cut once more and looked up  */
-                                 /* in the table's home index held in LDS (sub_index_kernel), 4 = one level, the table's BYTE   */
-                                 /* home index probed in the L2 instead of the tags (bucket_index_kernel; the default for scans */
-                                 /* without KG_F_COUNTERS)                                                                      */
+    int32_t part_levels;         /* partitioned only: what the tag pass probed in the L2 -- 1 = the tags (bucket_tag_kernel: scans  */
+                                 /* with KG_F_COUNTERS, KG_BIDX=0), 4 = the table's byte home index (bucket_index_kernel, the       */
+                                 /* default).  (2 and 3 were round 3's second partition level, removed in round 4.)                 */
 } kg_stats;
 
 typedef struct kg_table  kg_table;

@@ -998,74 +998,32 @@ __global__ void build_tags_kernel(const uint8_t *entries, uint64_t limit, uint64
 }
 
 // ---------------------------------------------------------------------------------------
-// Home index ("qidx"): 16 bits per slot h, built once per table, that answer "is the k-mer (quotient q, home slot h)
-// in the table?" without walking anything.  A query can only match a key whose OWN home slot is h (slot = value %
-// numSigs, KGJ:969), and under the reference's lookup (KGJ:944-1034: from the home slot forward, over occupied slots,
-// to the k-mer, the first empty slot or the end of the stream; never wrap) such a key is found iff it lies in the
-// occupied run that starts at h.  value = q * numSigs + h, so among the keys homed at h the quotient identifies the
-// key.  The word holds q % 31 (5 bits each, 31 = none) of the first three distinct keys of that run whose home
-// is h, and bit 15 = "there are more, or the run was not walked to its end": then, and only then, a query whose
-// quotient is not listed has to be walked the long way (a candidate flagged kWalkOn).  When every quotient is below
-// 31, i.e. numSigs > 20^8 / 31 (the KmerGuts table: 1.4e9 slots, quotients 0..18), the word is EXACT: listed = in the
-// table for certain (kScanOn), not listed and no "more" bit = not in the table for certain; P(more than three keys
-// share a home slot) is 0.2 % at load 0.5.  For smaller tables the 5 bits are a hash of the quotient: "not listed" is
-// still a certain miss, "listed" is a candidate that the generic walk checks (kWalkOn) -- same kernels, so that the
-// small tables of the tests and the fuzz run through them.  Negative keys are occupied and match nothing; a key stored
-// in front of its home slot or behind a hole is not reachable and not listed -- exactly the reference's lookup on
-// hand-made tables too.
-constexpr uint32_t kQidxNone = 0x7FFFu;
-constexpr uint32_t kQidxMaxWalk = 1024;        // slots walked per home slot before giving up with the "more" bit
-
-__global__ void build_qidx_kernel(const uint8_t *entries, const uint8_t *tags, uint64_t limit, uint64_t n_idx, uint64_t num_sigs,
-                                  uint64_t magic, uint16_t *idx)
-{
-    TableView tab;
-    tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic; tab.m35 = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n_idx; h += stride) {
-        uint32_t w = kQidxNone;
-        if (h < limit && tags[h] != kTagEmpty) {
-            uint32_t n = 0;
-            bool more = false;
-            uint64_t j = h;
-            for (; j < limit && j - h < kQidxMaxWalk; j++) {
-                if (tags[j] == kTagEmpty) break;
-                const uint2 a = *reinterpret_cast<const uint2 *>(entries + j * 24);
-                const int64_t key = (int64_t)(((uint64_t)a.y << 32) | a.x);
-                if (key < 0) continue;                      // occupied, matches no query (KGJ:1000-1004)
-                uint64_t q;
-                if (split_value((uint64_t)key, tab, &q) != h) continue;
-                const uint32_t q5 = (uint32_t)(q % 31u);
-                if ((w & 31u) == q5 || ((w >> 5) & 31u) == q5 || ((w >> 10) & 31u) == q5) continue;   // a duplicate: the first one wins
-                if (n == 3) { more = true; break; }
-                w = (w & ~(31u << (5 * n))) | (q5 << (5 * n));
-                n++;
-            }
-            if (j < limit && j - h >= kQidxMaxWalk) more = true;
-            if (more) w |= 0x8000u;
-        }
-        idx[h] = (uint16_t)w;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Byte home index ("bidx", round 4): the home index above squeezed into ONE byte per slot, so that a bucket of it is as
-// large as a bucket of tags (2 MiB for 2^21 slots: resident in an XCD's L2) and the ONE-level tag pass can probe it
+// Byte home index ("bidx", round 4): ONE byte per slot h, built once per table, that answers "is the k-mer (quotient q,
+// home slot h) in the table?" without walking anything.  A query can only match a key whose OWN home slot is h (slot =
+// value % numSigs, KGJ:969), and under the reference's lookup (KGJ:944-1034: from the home slot forward, over occupied slots,
+// to the k-mer, the first empty slot or the end of the stream; never wrap) such a key is found iff it lies in the occupied
+// run that starts at h.  value = q * numSigs + h, so among the keys homed at h the quotient identifies the key.  A bucket of
+// the index is as large as a bucket of tags (2 MiB for 2^21 slots: resident in an XCD's L2), so the tag pass can probe it
 // instead of the tags: one byte load per query, no fingerprint, no 16-tag window, no walk -- and, for the KmerGuts table,
 // no false candidate and no undecided window (the tag pass leaves 65 M candidates per Gbp for 36.7 M hits: fingerprint
 // collisions and, above all, home slots inside long occupied runs, whose 16-tag window decides nothing).
-// The byte lists the quotient CLASSES c = q % 19 of the keys homed at h that the reference's lookup can find (those in the
-// occupied run that starts at h, KGJ:944-1034):
+// The byte lists the quotient CLASSES c = q % 19 of the findable keys homed at h:
 //     0          no such key: a query with home slot h is a miss for certain
 //     1..19      one class: c = code - 1
 //     20..190    two classes c1 < c2 (171 pairs), bidx_pair_code
 //     191..254   three or more classes, hashed to six bits: bit (c % 6) of (code - 191) is set for every listed class; a query
 //                whose bit is clear is a miss for certain, one whose bit is set a candidate for the generic walk (1.4 % of
 //                the home slots at load 0.5, under half of the queries there)
-//     255        the run was not walked to its end (longer than kQidxMaxWalk): every query is a candidate for the walk
+//     255        the run was not walked to its end (longer than kHomeWalkMax): every query is a candidate for the walk
 // With numSigs > 20^8 / 19 (the KmerGuts table: 1.4e9 slots, quotients 0..18) a class IS the quotient and codes 1..190 are
 // exact: listed = in the table for certain (kScanOn: the verify pass scans the records from the home slot).  Smaller tables
-// fold their quotients into the 19 classes: "not listed" stays a certain miss, "listed" becomes a candidate for the walk.
+// fold their quotients into the 19 classes: "not listed" stays a certain miss, "listed" becomes a candidate for the walk --
+// same kernels, so that the small tables of the tests and the fuzz run through them.  Negative keys are occupied and match
+// nothing; a key stored in front of its home slot or behind a hole is not reachable and not listed -- exactly the
+// reference's lookup on hand-made tables too (tests/test_gpu_fullsize.py, hand-made clusters).
+// (Round 3's 16-bit home index, probed out of LDS behind a second partition level, was the idea's first form; the second
+//  level cost more than it saved and was removed in round 4: profiles/r03_two_level.md.)
+constexpr uint32_t kHomeWalkMax = 1024;        // slots walked per home slot before giving up with code 255
 constexpr uint32_t kBidxClasses = 19, kBidxPair0 = 20, kBidxHash0 = 191, kBidxMore = 255;
 constexpr uint32_t kBidxInexact = 0x80000000u;      // flag in the decoded word: a listed class is a candidate, not a hit
 
@@ -1117,7 +1075,7 @@ __global__ void build_bidx_kernel(const uint8_t *entries, const uint8_t *tags, u
         bool complete = true;
         if (h < limit && tags[h] != kTagEmpty) {
             uint64_t j = h;
-            for (; j < limit && j - h < kQidxMaxWalk; j++) {
+            for (; j < limit && j - h < kHomeWalkMax; j++) {
                 if (tags[j] == kTagEmpty) break;
                 const uint2 a = *reinterpret_cast<const uint2 *>(entries + j * 24);
                 const int64_t key = (int64_t)(((uint64_t)a.y << 32) | a.x);
@@ -1126,7 +1084,7 @@ __global__ void build_bidx_kernel(const uint8_t *entries, const uint8_t *tags, u
                 if (split_value((uint64_t)key, tab, &q) != h) continue;
                 mask |= 1u << (uint32_t)(q % kBidxClasses);
             }
-            if (j < limit && j - h >= kQidxMaxWalk) complete = false;
+            if (j < limit && j - h >= kHomeWalkMax) complete = false;
         }
         idx[h] = (uint8_t)bidx_encode(mask, complete);
     }

@@ -8,7 +8,6 @@
 #include "kg_device.hpp"
 #include "kg_aggregate.hpp"
 #include "kg_partition.hpp"
-#include "kg_partition2.hpp"
 #include "kg_order.hpp"
 
 #include <fcntl.h>
@@ -183,9 +182,6 @@ struct kg_table {
     bool own_entries = false;
     uint8_t *d_entries = nullptr;
     uint8_t *d_tags = nullptr;
-    uint16_t *d_qidx = nullptr;         // home index (kg_device.hpp, build_qidx_kernel) or null when the table is not eligible
-    uint64_t n_qidx = 0;                // its length in words (limit rounded up, filled with "no key")
-    bool qidx_exact = false;            // every quotient < 31: a listed quotient is a hit for certain
     uint8_t *d_bidx = nullptr;          // byte home index (kg_device.hpp, build_bidx_kernel): 1 byte per slot, limit + 64 bytes
     bool bidx_exact = false;            // every quotient < 19: its classes are quotients
     uint64_t tail_start = 0;            // first slot of the occupied run that ends at the end of the record stream
@@ -198,7 +194,6 @@ struct kg_table {
     size_t scatter_lds[2] = {0, 0};  // dynamic LDS the scatter kernel (DNA / protein) has been allowed so far
     size_t hist_lds = 48 * 1024;     // ... and the hit histogram kernel (kg_order.hpp)
     size_t place_lds[2] = {48 * 1024, 48 * 1024};   // ... and group_place_kernel<DNA / AA>
-    size_t probe2_lds[3] = {0, 0, 0};   // ... and the second-level probe kernels (tags without / with counters, home index)
     hipEvent_t ev[8] = {};
     // Pinned host words for the few counters a scan reads back (a hipMemcpyAsync to pageable memory blocks the host per
     // copy; to pinned memory it does not): [0..47] d_pc, [48..79] d_ovfc (as 64 x u32), [80..87] d_totals, [88] CALL total
@@ -282,17 +277,6 @@ int table_finish(kg_table *t)
     hipLaunchKernelGGL(kg::build_tags_kernel, dim3(grid), dim3(256), 0, t->stream, t->d_entries, t->limit, n_tags,
                        (uint64_t)t->num_sigs, t->magic, t->d_tags, d_occ);
     HIP_TRY(hipGetLastError());
-    // the home index: 2 bytes per slot, for every table the scatter pass applies to (64 <= numSigs < 2^31); exact when every
-    // quotient of a k-mer is below 31 (numSigs > 20^8 / 31).  KG_QIDX=0 leaves it out (the tag kernels serve every table).
-    t->qidx_exact = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1 <= 31;
-    if (t->m35 != 0 && t->limit > 0 && env_u32("KG_QIDX", 1u) != 0) {
-        t->n_qidx = (t->limit + 7) / 8 * 8 + 8;
-        HIP_TRY(hipMalloc((void **)&t->d_qidx, t->n_qidx * 2));
-        const uint64_t wantq = (t->n_qidx + 255) / 256;
-        hipLaunchKernelGGL(kg::build_qidx_kernel, dim3((uint32_t)std::min<uint64_t>(wantq, 256ull * 32)), dim3(256), 0, t->stream,
-                           t->d_entries, t->d_tags, t->limit, t->n_qidx, (uint64_t)t->num_sigs, t->magic, t->d_qidx);
-        HIP_TRY(hipGetLastError());
-    }
     // the byte home index: what the one-level tag pass probes instead of the tags (KG_BIDX=0 leaves it out)
     t->bidx_exact = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1 <= kg::kBidxClasses;
     if (t->m35 != 0 && t->limit > 0 && env_u32("KG_BIDX", 1u) != 0) {
@@ -575,7 +559,6 @@ void kg_table_close(kg_table *t)
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     if (t->own_entries && t->d_entries) (void)hipFree(t->d_entries);
     if (t->d_tags) (void)hipFree(t->d_tags);
-    if (t->d_qidx) (void)hipFree(t->d_qidx);
     if (t->d_bidx) (void)hipFree(t->d_bidx);
     t->cache.release_all();
     t->pins.release_all();
@@ -976,48 +959,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         }
         if ((rc = sc.get(&d_pc, 48))) return rc;
         unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
-        // Second partition level (kg_partition2.hpp): the entries of a bucket are cut once more, by sub-bucket of 2^sshift
-        // slots, and probed against tags held in LDS.  KG_PART_LEVELS: 1 = tag pass out of the L2 (bucket_tag_kernel),
-        // 2 = sub-scatter + LDS probe.  KG_PART_SUBSHIFT: log2 of a sub-bucket's slots (tags = LDS bytes per workgroup).
-        uint32_t levels = env_u32("KG_PART_LEVELS", 1u);
-        // with the home index (2 bytes per slot in LDS, no counters kernel) a sub-bucket is at most 2^15 slots
-        const bool use_qidx = levels == 2 && t->d_qidx != nullptr && !counters && env_u32("KG_QIDX", 1u) != 0;
-        uint32_t sshift = std::min(use_qidx ? 15u : 17u, env_u32("KG_PART_SUBSHIFT", use_qidx ? 15u : 16u));
-        if (sshift + 6 < part_shift) sshift = part_shift - 6;                         // at most kMaxSub sub-buckets per bucket
-        if (sshift + 1 > part_shift) sshift = part_shift - 1;
-        if (levels != 2 || part_shift < 9 || sshift < 8) levels = 1;
-        // one level: the tag pass on the byte home index instead of the tags (bucket_index_kernel) unless the scan counts the
-        // slots it inspects (the walk the index avoids) or KG_BIDX=0
-        const bool use_bidx = levels == 1 && t->d_bidx != nullptr && !counters && env_u32("KG_BIDX", 1u) != 0;
-        const uint32_t n_sub = levels == 2 ? 1u << (part_shift - sshift) : 0u;
-        const uint64_t n_sub_total = (uint64_t)part_buckets * n_sub;                  // sub-bucket arrays per chunk
-        const uint32_t n_items2 = levels == 2 ? (uint32_t)((t->limit + (1ull << sshift) - 1) >> sshift) : 0u;
-        uint32_t cap2 = 0;
-        uint64_t *d_ent2 = nullptr;
-        uint32_t *d_cur2 = nullptr;
-        if (levels == 2) {
-            // a sub-bucket's array: 1.25 x the mean if every window of the largest chunk were valid and hashed uniformly, + 6
-            // sigma.  (Slots are value % numSigs: a sub-bucket is ~18 runs of consecutive k-mer values, i.e. of k-mers that share
-            // their first four or five residues, and residue frequencies differ -- six-codon against one-codon amino acids --
-            // so sub-buckets fill far less evenly than uniform hashing would: at 1.0 x, 0.24 % of the entries of the 1 Gbp
-            // bench spilled to the overflow list, where the DNA's 32 % of invalid windows were the only headroom.)
-            const double mean2 = (double)max_chunk * WIN / (double)n_sub_total * (env_u32("KG_PART_SLACK", 100u) / 100.0) * 1.25;
-            cap2 = env_u32("KG_PART_CAP2", (uint32_t)(((uint64_t)(mean2 + 6.0 * std::sqrt(mean2) + 64.0) + 15) / 16 * 16));
-            cap2 = std::max(16u, (cap2 + 15u) / 16u * 16u);
-            if ((rc = sc.get(&d_ent2, (size_t)(n_sub_total * cap2 * n_chunks_p)))) return rc;
-            if ((rc = sc.get(&d_cur2, (size_t)(n_sub_total * n_chunks_p)))) return rc;
-            const size_t tile_lds = use_qidx ? ((size_t)2 << sshift) : ((size_t)1 << sshift) + 16;
-            if (use_qidx) {
-                if (t->probe2_lds[2] < tile_lds) {
-                    HIP_TRY(hipFuncSetAttribute((const void *)kg::sub_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
-                    t->probe2_lds[2] = tile_lds;
-                }
-            } else if (t->probe2_lds[counters ? 1 : 0] < tile_lds) {
-                if (counters) HIP_TRY(hipFuncSetAttribute((const void *)kg::sub_probe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
-                else HIP_TRY(hipFuncSetAttribute((const void *)kg::sub_probe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
-                t->probe2_lds[counters ? 1 : 0] = tile_lds;
-            }
-        }
+        // the tag pass on the byte home index instead of the tags (bucket_index_kernel) unless the scan counts the slots it
+        // inspects (the walk the index avoids) or KG_BIDX=0
+        const bool use_bidx = t->d_bidx != nullptr && !counters && env_u32("KG_BIDX", 1u) != 0;
         const size_t lds = kg::scatter_lds_bytes<AA>(part_buckets);
         if (t->scatter_lds[AA ? 1 : 0] < lds) {         // once per table (and geometry): the call costs tens of microseconds
             HIP_TRY(hipFuncSetAttribute((const void *)kg::part_scatter_kernel<AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1090,7 +1034,6 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 cl.p[5] = d_next; cl.words[5] = (uint64_t)next_stride * n_chunks_p;
                 cl.p[6] = d_ghist; cl.words[6] = (uint64_t)groups_stride * n_chunks_p;
                 cl.p[7] = nullptr; cl.words[7] = 0;
-                if (levels == 2) { cl.n = 8; cl.p[7] = d_cur2; cl.words[7] = n_sub_total * n_chunks_p; }
                 uint64_t most = 1;                                      // the grid follows the LARGEST list (the kernel strides)
                 for (int k = 0; k < cl.n; k++) most = std::max(most, cl.words[k]);
                 most /= 4;
@@ -1124,13 +1067,6 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                                    d_blocks, lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
                                    cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, ovfc_c + 1, d_lowc + lo, d_ctr);
                 hipStream_t s2 = t->stream2, s3 = t->stream3;
-                // KG_LOWC_STREAM=1: the (usually idle) low-complexity kernel runs behind its chunk's scatter pass on the scatter
-                // stream -- where the CUs have just been vacated -- instead of in front of the chunk's tag pass on the tag stream
-                const bool lowc_on_scatter = env_u32("KG_LOWC_STREAM", 0u) != 0;
-                if (lowc_on_scatter)
-                    hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(lowc_grid), dim3(64 * kg::kLowcWaves), 0, t->stream, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
-                                       t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
-                                       ovf_bucket_c, ovf_ent_c, d_ctr);
                 HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
                 HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
                 // the low-complexity blocks the scatter pass set aside (usually none: every workgroup reads the count and
@@ -1138,34 +1074,13 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 // 4.9 KB of LDS fit beside a resident scatter workgroup (153 KB of a CU's 160): with four-wave workgroups
                 // (15.8 KB) the kernel -- and the tag pass behind it -- waited for the NEXT chunk's scatter pass to leave
                 // the CUs (profiles/r02_pipeline.md).
-                if (!lowc_on_scatter)
-                    hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(lowc_grid), dim3(64 * kg::kLowcWaves), 0, s2, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
-                                       t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
-                                       ovf_bucket_c, ovf_ent_c, d_ctr);
+                hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(lowc_grid), dim3(64 * kg::kLowcWaves), 0, s2, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
+                                   t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
+                                   ovf_bucket_c, ovf_ent_c, d_ctr);
 #define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
                     candused_c, ccur_c, ccap, d_ctr
 #define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_ctr
-                if (levels == 2) {
-                    uint64_t *ent2_c = d_ent2 + (uint64_t)c * n_sub_total * cap2;
-                    uint32_t *cur2_c = d_cur2 + (uint64_t)c * n_sub_total;
-                    const uint32_t rpi = std::max(1u, std::min(n_wg, env_u32("KG_SUB_RPI", 16u)));
-                    const uint64_t items1 = (uint64_t)part_buckets * ((n_wg + rpi - 1) / rpi);
-                    const uint32_t grid1 = (uint32_t)std::min<uint64_t>(items1, std::max(1u, env_u32("KG_SUB_GRID", 256u * 4u)));
-                    hipLaunchKernelGGL(kg::sub_scatter_kernel, dim3(grid1), dim3(kg::kSubThreads), 0, s2, ent_c, fill_c, n_wg, cap,
-                                       part_buckets, part_shift, sshift, rpi, next_c, ent2_c, cur2_c, cap2, ovfc_c, ovf_cap,
-                                       ovf_bucket_c, ovf_ent_c);
-                    const size_t tile_lds = use_qidx ? ((size_t)2 << sshift) : ((size_t)1 << sshift) + 16;
-                    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / (tile_lds + 256)));
-                    const uint32_t grid2 = std::min(n_items2, std::max(1u, env_u32("KG_PROBE2_GRID", 256u * per_cu)));
-#define KG_TAG2_ARGS t->d_tags, t->limit, ent2_c, cur2_c, cap2, n_items2, part_shift, sshift, next_c + 64, cand_c, candused_c, ccur_c, ccap, d_ctr
-                    if (use_qidx)
-                        hipLaunchKernelGGL(kg::sub_index_kernel, dim3(grid2), dim3(kg::kIndexThreads), tile_lds, s2, t->d_qidx, t->n_qidx,
-                                           t->qidx_exact ? 1u : 0u, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent2_c, cur2_c, cap2, n_items2, part_shift,
-                                           sshift, next_c + 64, cand_c, candused_c, ccur_c, ccap, d_ctr);
-                    else if (counters) hipLaunchKernelGGL((kg::sub_probe_kernel<true>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
-                    else hipLaunchKernelGGL((kg::sub_probe_kernel<false>), dim3(grid2), dim3(kg::kProbe2Threads), tile_lds, s2, KG_TAG2_ARGS);
-#undef KG_TAG2_ARGS
-                } else if (use_bidx) {
+                if (use_bidx) {
 #define KG_INDEX_ARGS t->d_bidx, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent_c, fill_c, n_wg, cap, \
                       part_buckets, part_shift, probe_grab, next_c, cand_c, candused_c, ccur_c, ccap, d_ctr
 #define KG_INDEX_LAUNCH(R, X) hipLaunchKernelGGL((kg::bucket_index_kernel<kg::kIndexN, R, X>), dim3(index_grid), dim3(256), 0, s2, KG_INDEX_ARGS)
@@ -1287,10 +1202,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             if (getenv("KG_DEBUG"))
                 fprintf(stderr, "[kg] partition attempt %d: %u chunks (largest %llu of %llu blocks), overflow groups <= %u (cap %u), hit list <= %llu "
                                 "(cap %llu), candidates <= %llu (cap %llu), regions/chunk %llu x %u entries, %u buckets, shift %u, %u scatter "
-                                "workgroups, hits %llu, levels %u%s (sub-bucket shift %u, %u entries each)\n",
+                                "workgroups, hits %llu, %s\n",
                         attempt, n_chunks_p, (unsigned long long)max_chunk, (unsigned long long)nblocks, max_ovf, ovf_cap,
                         (unsigned long long)need_u, (unsigned long long)ucap, (unsigned long long)need_c, (unsigned long long)ccap,
-                        (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg, (unsigned long long)h_pc[16 + n_chunks_p], levels, use_qidx ? " + home index" : "", sshift, cap2);
+                        (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg, (unsigned long long)h_pc[16 + n_chunks_p], use_bidx ? "byte home index" : "tags");
             if (guard) { too_skewed = true; st.fallback = 2; break; }    // the scatter pass's spin guard fired: direct path
             if (max_ovf > ovf_cap) { too_skewed = true; st.fallback = 1; break; }   // more overflow than provisioned: direct path
             n_hits = h_pc[16 + n_chunks_p];
@@ -1320,7 +1235,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             part_done = true;
             st.partitioned = 1;
             st.part_chunks = (int32_t)n_chunks_p; st.part_buckets = (int32_t)part_buckets; st.part_shift = (int32_t)part_shift;
-            st.part_levels = (int32_t)(levels == 2 && use_qidx ? 3 : use_bidx ? 4 : levels);
+            st.part_levels = use_bidx ? 4 : 1;
         }
     } while (0);
     if (!part_done) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long differential fuzz against the CPU oracle (test infrastructure; not collected by pytest):
     python tests/fuzz_long.py [n_workloads=400] [first_seed=1000]
-Every workload of tests/fuzz_workloads.py through the three scan strategies, records, event bytes, counters and flags compared
+Every workload of tests/fuzz_workloads.py through the scan strategies (direct; partitioned on the byte home index and on the tags, with and without counters), records, event bytes, counters and flags compared
 with the oracle.  Prints one JSON summary line; exit code 1 on the first difference."""
 import json
 import os
@@ -15,7 +15,7 @@ from fuzz_workloads import workloads          # noqa: E402
 from helpers import assert_same_records       # noqa: E402
 
 KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_SLACK", "KG_TEST_TINY_LISTS", "KG_PART_OVF_GROUPS",
-         "KG_PART_LEVELS", "KG_PART_SUBSHIFT", "KG_PART_CAP2", "KG_SUB_RPI")
+         "KG_BIDX", "KG_INDEX_R")
 
 
 def main():
@@ -30,7 +30,7 @@ def main():
             p = w["params"]
             ora = kgo.run(w["img"], w["raw"], w["off"], lookup_mode=1, **p)
             with hotpath.SignatureTable.from_bytes(w["img"]) as tab:
-                for mode in ("0", "1", "2"):           # direct, partitioned, partitioned with the second level
+                for mode in ("0", "1", "2"):           # direct, partitioned (byte home index / tags with counters), partitioned on the tags only
                     for k in KNOBS:
                         os.environ.pop(k, None)
                     os.environ["KG_PARTITION"] = "0" if mode == "0" else "1"
@@ -42,15 +42,15 @@ def main():
                         assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s %s" % (seed, w["it"], mode, w["env"], w["env2"] if mode == "2" else ""))
                         assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
                         n_part += r.stats["partitioned"]
-                    if mode == "2":                        # the home-index kernel (no KG_F_COUNTERS variant)
+                    if mode != "0":                        # without KG_F_COUNTERS: the byte-index kernel ("1") / the plain tag kernel ("2")
                         with tab.scan(w["raw"], w["off"], hotpath.Params(**p)) as r:
-                            assert_same_records(r, ora, "fuzz seed %d it %d home index %s %s" % (seed, w["it"], w["env"], w["env2"]))
+                            assert_same_records(r, ora, "fuzz seed %d it %d mode %s no counters %s" % (seed, w["it"], mode, w["env"]))
             done += 1
             calls += len(ora["calls"])
             hits += len(ora["hits"])
             if done >= n:
                 break
-    print(json.dumps({"workloads": done, "scans": 4 * done, "ran_partitioned": n_part, "oracle_hits": hits, "oracle_calls": calls,
+    print(json.dumps({"workloads": done, "scans": 5 * done, "ran_partitioned": n_part, "oracle_hits": hits, "oracle_calls": calls,
                       "all_identical": True}))
 
 

@@ -1,6 +1,6 @@
 """Random small workloads for the differential fuzz tests (tests/test_gpu_fuzz.py) and tools/fuzz_strategies.py:
 tables of various sizes and loads, DNA / protein, ragged lengths, planted signatures, low-complexity runs, invalid
-characters, parameters, and knobs that force chunking, tiny regions and tiny lists."""
+characters, parameters, and knobs that force chunking, tiny regions, tiny lists and several regions per hand-out."""
 import numpy as np
 
 
@@ -52,11 +52,8 @@ def workloads(iters, seed):
             env["KG_TEST_TINY_LISTS"] = "1"
         if rng.integers(0, 8) == 0:
             env["KG_PART_OVF_GROUPS"] = str(int(rng.choice([1, 64])))
-        # the second partition level (used by the callers' "2" mode): sub-bucket size, and now and then sub-bucket arrays
-        # far too small, so that entries spill to the overflow list
-        env2 = {"KG_PART_LEVELS": "2", "KG_PART_SUBSHIFT": str(int(rng.choice([8, 9, 10, 12, 16])))}
-        if rng.integers(0, 3) == 0:
-            env2["KG_PART_CAP2"] = str(int(rng.choice([16, 64, 256])))
-        if rng.integers(0, 4) == 0:
-            env2["KG_SUB_RPI"] = str(int(rng.choice([1, 3, 256])))
+        if rng.integers(0, 2) == 0:                                  # regions per hand-out of the byte-index pass
+            env["KG_INDEX_R"] = str(int(rng.choice([1, 2, 4])))
+        # the callers' "2" mode: the tag kernels for every scan (no byte home index)
+        env2 = {"KG_BIDX": "0"}
         yield dict(env2=env2, it=it, aa=aa, num_sigs=num_sigs, load=load, img=img, raw=raw, off=off, params=params, env=env)

@@ -24,7 +24,7 @@ def assert_same_records(gpu, ora, what=""):
     assert gpu.stats["lookup_ran_off"] == int(ora["lookup_aborted"]), what + " lookup_ran_off"
     import os
     mode = os.environ.get("KG_PARTITION")
-    knobs = any(os.environ.get(k) is not None for k in ("KG_PART_OVF_GROUPS", "KG_PART_SLACK", "KG_PART_CAP2"))
+    knobs = any(os.environ.get(k) is not None for k in ("KG_PART_OVF_GROUPS", "KG_PART_SLACK"))
     if not knobs:       # 1 = overflow beyond the list, 2 = spin guard of the scatter pass: never without a forcing knob
         assert gpu.stats["fallback"] == 0, "%s: partitioned attempt thrown away (fallback %d)" % (what, gpu.stats["fallback"])
     if mode == "0":
@@ -32,11 +32,8 @@ def assert_same_records(gpu, ora, what=""):
     if mode == "1" and gpu.stats["n_blocks"] > 0 and os.environ.get("KG_PART_OVF_GROUPS") is None and os.environ.get("KG_PART_SLACK") is None and _partition_fits(gpu.stats):
         assert gpu.stats["partitioned"] == 1, what + ": the partitioned strategy fell back to direct probing"
     if gpu.stats["partitioned"] == 1:
-        # one level: 4 = the byte home index probed in the L2 (scans without KG_F_COUNTERS), 1 = the tags
+        # what the tag pass probed: 4 = the byte home index (scans without KG_F_COUNTERS), 1 = the tags
         want = 4 if os.environ.get("KG_BIDX", "1") != "0" and gpu.stats["windows_valid"] < 0 else 1
-        if os.environ.get("KG_PART_LEVELS") == "2" and gpu.stats["part_shift"] >= 9:
-            # 3 = home index in LDS (no counters kernel: KG_F_COUNTERS scans keep the tag kernels), 2 = tags in LDS
-            want = 3 if os.environ.get("KG_QIDX", "1") != "0" and gpu.stats["windows_valid"] < 0 else 2
         assert gpu.stats["part_levels"] == want, "%s: partition levels %d, wanted %d" % (what, gpu.stats["part_levels"], want)
 
 

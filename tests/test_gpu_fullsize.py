@@ -376,7 +376,7 @@ def test_copy_hits_and_zero_copy_views(hp):
             r.copy_hits(len(h) - 10, 11)
 
 
-@pytest.mark.parametrize("strategy", ["direct", "partitioned", "partitioned2"])
+@pytest.mark.parametrize("strategy", ["direct", "partitioned", "partitioned_tags"])
 def test_config1_plumbing_at_its_stated_size(hp, oracle, strategy, monkeypatch):
     """BASELINE config 1 as written: 10 000 proteins of ~300 aa against a 1 000 003-slot table holding 500 000 signatures
     (half of them the sequences' own 8-mers), AA mode, through the whole C ABI: every record against the oracle's literal
@@ -388,7 +388,7 @@ def test_config1_plumbing_at_its_stated_size(hp, oracle, strategy, monkeypatch):
     img = synth.table_image(rec)
     sb = seq.numpy().tobytes()
     monkeypatch.setenv("KG_PARTITION", "0" if strategy == "direct" else "1")
-    monkeypatch.setenv("KG_PART_LEVELS", "2" if strategy == "partitioned2" else "1")
+    monkeypatch.setenv("KG_BIDX", "0" if strategy == "partitioned_tags" else "1")
     # the same keys with ONE function per protein for the signatures drawn from it: the reference's defaults then CALL
     seq_c, off_c, rec_c, placed_c = synth.plumbing_config(coherent=True)
     assert placed_c == placed and np.array_equal(off_c, off)
@@ -409,10 +409,10 @@ def test_config1_plumbing_at_its_stated_size(hp, oracle, strategy, monkeypatch):
                         assert r.stats["windows_valid"] == o1["windows_valid"] and r.stats["slots_inspected"] == o1["slots_inspected"]
 
 
-def test_two_level_scan_and_home_index_at_full_size(hp, oracle, full_table, monkeypatch):
-    """KG_PART_LEVELS=2 on BASELINE config 3: the second partition level with the tags in LDS (KG_F_COUNTERS scans) and with
-    the table's home index in LDS (exact for this table: quotients 0..18) must leave the records of the default
-    one-level scan, compared over the whole result on the device, and the oracle's on contigs from every chunk."""
+def test_byte_home_index_against_the_tags_at_full_size(hp, oracle, full_table, monkeypatch):
+    """BASELINE config 3 through the two things the tag pass can probe: the table's byte home index (the default; exact for
+    this table: quotients 0..18) and the tags (KG_BIDX=0, and every KG_F_COUNTERS scan): the same records over the whole
+    1 Gbp result, compared on the device, the oracle's on contigs from every chunk, and the same counters either way."""
     from kmergutsjava_amd import synth
     dev = torch.device("cuda", 0)
     tab = full_table["tab"]
@@ -421,39 +421,33 @@ def test_two_level_scan_and_home_index_at_full_size(hp, oracle, full_table, monk
     seq = synth.random_dna(int(off[-1]), 302, dev)
     torch.cuda.synchronize()
     monkeypatch.delenv("KG_PARTITION", raising=False)
-    monkeypatch.setenv("KG_PART_LEVELS", "1")
     with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as r1:
-        assert r1.stats["partitioned"] == 1 and r1.stats["part_levels"] == 4          # one level, byte home index (the default)
+        assert r1.stats["partitioned"] == 1 and r1.stats["part_levels"] == 4 and r1.stats["fallback"] == 0, r1.stats
+        idx = synth.spread_sample(off, groups=4, per_group=10, max_bp_per_group=1_500_000)
+        _oracle_sample(oracle, full_table["image"](), seq, off, idx, r1, "byte home index")
         monkeypatch.setenv("KG_BIDX", "0")
         with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as r0:
             assert r0.stats["part_levels"] == 1 and r0.stats["fallback"] == 0, r0.stats
-            _same_on_device(r1, r0, "one level: byte home index vs tags")
+            _same_on_device(r1, r0, "byte home index vs tags")
             assert r0.stats["lookup_ran_off"] == r1.stats["lookup_ran_off"]
+        with tab.scan(None, off, hp.Params(counters=True), device_ptr=seq.data_ptr()) as rc0:
+            c0 = (rc0.stats["windows_valid"], rc0.stats["slots_inspected"])
         monkeypatch.delenv("KG_BIDX")
-        monkeypatch.setenv("KG_PART_LEVELS", "2")
-        with tab.scan(None, off, hp.Params(), device_ptr=seq.data_ptr()) as r3:
-            assert r3.stats["part_levels"] == 3 and r3.stats["fallback"] == 0, r3.stats
-            _same_on_device(r1, r3, "one level vs two levels + home index")
-            assert r3.stats["lookup_ran_off"] == r1.stats["lookup_ran_off"]
-            idx = synth.spread_sample(off, groups=4, per_group=10, max_bp_per_group=1_500_000)
-            _oracle_sample(oracle, full_table["image"](), seq, off, idx, r3, "two levels + home index")
-        with tab.scan(None, off, hp.Params(counters=True), device_ptr=seq.data_ptr()) as r2:
-            assert r2.stats["part_levels"] == 2 and r2.stats["fallback"] == 0, r2.stats
-            _same_on_device(r1, r2, "one level vs two levels (tags in LDS)")
-        monkeypatch.setenv("KG_PART_LEVELS", "1")
         with tab.scan(None, off, hp.Params(counters=True), device_ptr=seq.data_ptr()) as rc:
-            assert (rc.stats["windows_valid"], rc.stats["slots_inspected"]) == (r2.stats["windows_valid"], r2.stats["slots_inspected"])
+            assert rc.stats["part_levels"] == 1                       # counters: the tag kernels either way
+            _same_on_device(r1, rc, "byte home index vs tags with counters")
+            assert (rc.stats["windows_valid"], rc.stats["slots_inspected"]) == c0
 
 
 @pytest.mark.parametrize("n", [900_000_011, 1_400_000_029])
 def test_home_index_on_hand_made_clusters_in_a_full_size_table(hp, oracle, monkeypatch, n):
-    """The exact home index (numSigs > 20^8 / 31) on the cases it could get wrong, planted by hand into an otherwise
-    empty 900 000 011-slot table and queried as proteins: four and five keys sharing one home slot (the 'more' bit), a key
-    behind a NEGATIVE whichKmer, a key behind a hole (not reachable), a key in front of its home slot (not reachable), the
-    same key twice in one run (the first one wins), and keys in the occupied run that ends at the end of the record stream
-    (lookup_ran_off).  Oracle: literal merge-join and direct probing."""
-    # n = 900 000 011: quotients up to 28 -- exact for the 16-bit index (< 31), folded into classes for the byte index (>= 19);
-    # n = 1 400 000 029: quotients up to 18 -- exact for both (the KmerGuts table's regime)
+    """The byte home index on the cases it could get wrong, planted by hand into an otherwise empty full-size table and
+    queried as proteins: two keys sharing one home slot (a pair code), three and five (hashed codes: a candidate the walk has
+    to refute, a certain miss), a key behind a NEGATIVE whichKmer, a key behind a hole (not reachable), a key in front of its
+    home slot (not reachable), the same key twice in one run (the first one wins), and keys in the occupied run that ends at the
+    end of the record stream (lookup_ran_off).  Oracle: literal merge-join and direct probing.
+    n = 900 000 011: quotients up to 28, folded into the index's 19 classes (every listed class is only a candidate);
+    n = 1 400 000 029: quotients up to 18 -- a class is the quotient, codes 1..190 are exact (the KmerGuts table's regime)."""
     from kmergutsjava_amd import synth
     import kat_cases as K
     dev = torch.device("cuda", 0)
@@ -470,11 +464,11 @@ def test_home_index_on_hand_made_clusters_in_a_full_size_table(hp, oracle, monke
         rec[slot] = row
 
     queries = []                                   # (k-mer value, expected oI or None)
-    h = 1000                                       # five keys homed at slot 1000: quotients 0..4 -> the fifth sets nothing new, 'more'
+    h = 1000                                       # five keys homed at slot 1000: quotients 0..4 (a hashed code: class bits 0..4)
     for q in range(5):
         put(h + q, q * n + h, 10 + q, 2)
         queries.append((q * n + h, 10 + q))
-    queries.append((7 * n + h, None))              # same home, unknown quotient: walks the run (more bit), not found
+    queries.append((7 * n + h, None))              # same home, unknown quotient (7 % 6 = 1: its bit is set): a candidate, walked, not found
     h = 5000                                       # negative key at the home slot, the real key behind it
     put(h, -12345, 1, 1); put(h + 1, 3 * n + h, 21, 2)
     queries.append((3 * n + h, 21))
@@ -523,14 +517,14 @@ def test_home_index_on_hand_made_clusters_in_a_full_size_table(hp, oracle, monke
                 got = sorted({int(x["oI"]) for x in ora0["hits"][ora0["hits"]["container"] == k]})
                 assert got == ([oi] if oi is not None else []), (k, v, got, oi)
             assert bool(ora0["lookup_aborted"]) == with_run_off
-            for levels, counters in (("1", False), ("1", True), ("2", True), ("2", False)):
-                monkeypatch.setenv("KG_PART_LEVELS", levels)
+            for bidx, counters in (("1", False), ("1", True), ("0", False)):
+                monkeypatch.setenv("KG_BIDX", bidx)
                 with tab.scan(sb, off, hp.Params(aa=True, min_hits=2, counters=counters)) as r:
                     assert r.stats["partitioned"] == 1
-                    # 4: the byte home index in the L2, 1: the tags in the L2, 3: the 16-bit home index in LDS, 2: the tags in LDS
-                    assert r.stats["part_levels"] == ((1 if counters else 4) if levels == "1" else 2 if counters else 3)
-                    assert r.hits().tobytes() == ora0["hits"].tobytes(), (levels, counters, with_run_off)
+                    # 4: the byte home index, 1: the tags (with and without counters)
+                    assert r.stats["part_levels"] == (4 if bidx == "1" and not counters else 1)
+                    assert r.hits().tobytes() == ora0["hits"].tobytes(), (bidx, counters, with_run_off)
                     assert r.calls().tobytes() == ora0["calls"].tobytes() and r.otu().tobytes() == ora0["otu"].tobytes()
-                    assert r.stats["lookup_ran_off"] == int(with_run_off), (levels, counters, r.stats["lookup_ran_off"])
+                    assert r.stats["lookup_ran_off"] == int(with_run_off), (bidx, counters, r.stats["lookup_ran_off"])
     del rec, host
     torch.cuda.empty_cache()

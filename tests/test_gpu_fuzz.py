@@ -1,6 +1,6 @@
 """Differential fuzz (tests/fuzz_workloads.py: random tables, sequences with planted signatures and low-complexity
 runs, parameters, forced chunking, tiny regions and lists):
-  * the scan strategies (direct, partitioned, partitioned with the second level) against the CPU oracle, record for record, events included;
+  * the scan strategies (direct; partitioned on the byte home index and on the tags) against the CPU oracle, record for record, events included;
   * tools/fuzz_strategies.py (direct vs partitioned only, no oracle) as a subprocess."""
 import json
 import os
@@ -15,18 +15,18 @@ from helpers import assert_same_records
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_SLACK", "KG_TEST_TINY_LISTS", "KG_PART_OVF_GROUPS",
-         "KG_PART_LEVELS", "KG_PART_SUBSHIFT", "KG_PART_CAP2", "KG_SUB_RPI")
+         "KG_BIDX", "KG_INDEX_R")
 
 
 @pytest.mark.parametrize("seed", [21, 22])
 def test_both_strategies_against_the_oracle(oracle, monkeypatch, seed):
     from kmergutsjava_amd import hotpath
-    n_part = n_index = n_bidx = 0
+    n_part = n_bidx = n_tags = 0
     for w in workloads(25, seed):
         p = w["params"]
         ora = oracle.run(w["img"], w["raw"], w["off"], lookup_mode=1, **p)
         with hotpath.SignatureTable.from_bytes(w["img"]) as tab:
-            for mode in ("0", "1", "2"):               # direct, partitioned, partitioned with the second level
+            for mode in ("0", "1", "2"):               # direct, partitioned (byte home index / tags with counters), partitioned on the tags only
                 for k in KNOBS:
                     monkeypatch.delenv(k, raising=False)
                 monkeypatch.setenv("KG_PARTITION", "0" if mode == "0" else "1")
@@ -41,13 +41,12 @@ def test_both_strategies_against_the_oracle(oracle, monkeypatch, seed):
                     assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
                     n_part += r.stats["partitioned"]
                 if mode != "0":
-                    # without KG_F_COUNTERS the entries are looked up in the table's home indexes: one level -> the byte index
-                    # in the L2 (bucket_index_kernel), two levels -> the 16-bit index in LDS (sub_index_kernel)
+                    # without KG_F_COUNTERS: mode "1" probes the table's byte home index (bucket_index_kernel), mode "2" the tags
                     with tab.scan(w["raw"], w["off"], hotpath.Params(**p)) as r:
-                        assert_same_records(r, ora, "fuzz seed %d it %d home index %s %s" % (seed, w["it"], w["env"], w["env2"] if mode == "2" else ""))
-                        n_index += r.stats["part_levels"] == 3
+                        assert_same_records(r, ora, "fuzz seed %d it %d mode %s no counters %s" % (seed, w["it"], mode, w["env"]))
                         n_bidx += r.stats["part_levels"] == 4
-    assert n_part >= 30 and n_index >= 10 and n_bidx >= 10
+                        n_tags += r.stats["part_levels"] == 1
+    assert n_part >= 30 and n_bidx >= 10 and n_tags >= 10
 
 
 def test_strategies_agree_on_random_workloads():

@@ -47,12 +47,12 @@ def test_a_second_concurrent_scan_on_one_table_is_turned_away(monkeypatch):
         assert tab.live_device_bytes() == 0
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2"])
+@pytest.mark.parametrize("mode", ["0", "1", "2"])          # direct, partitioned on the byte home index, partitioned on the tags
 def test_a_scan_that_fails_in_the_middle_leaves_nothing_behind(monkeypatch, mode):
     from kmergutsjava_amd import hotpath, _native as N
     img, sb, off = _workload()
     monkeypatch.setenv("KG_PARTITION", "0" if mode == "0" else "1")
-    monkeypatch.setenv("KG_PART_LEVELS", "2" if mode == "2" else "1")
+    monkeypatch.setenv("KG_BIDX", "0" if mode == "2" else "1")
     with hotpath.SignatureTable.from_bytes(img) as tab:
         with tab.scan(sb, off, hotpath.Params()) as r0:
             want = (r0.hits().tobytes(), r0.calls().tobytes())
@@ -75,15 +75,15 @@ def test_a_scan_that_fails_in_the_middle_leaves_nothing_behind(monkeypatch, mode
             assert (r.hits().tobytes(), r.calls().tobytes()) == want
 
 
-@pytest.mark.parametrize("levels", ["1", "2"])
-def test_resize_and_rerun_hands_every_list_block_back(monkeypatch, levels):
+@pytest.mark.parametrize("bidx", ["1", "0"])
+def test_resize_and_rerun_hands_every_list_block_back(monkeypatch, bidx):
     """KG_TEST_TINY_LISTS starts the hit / candidate lists (and with them the two ordering buffers) at one chunk: the
     attempt is thrown away and redone with the exact sizes.  Every block of the first attempt has to be back in the
     cache once the result is closed (round 3 leaked the ordering buffers of the first attempt until kg_table_close)."""
     from kmergutsjava_amd import hotpath
     img, sb, off = _workload()
     monkeypatch.setenv("KG_PARTITION", "1")
-    monkeypatch.setenv("KG_PART_LEVELS", levels)
+    monkeypatch.setenv("KG_BIDX", bidx)
     with hotpath.SignatureTable.from_bytes(img) as tab:
         with tab.scan(sb, off, hotpath.Params()) as r0:
             want = (r0.hits().tobytes(), r0.calls().tobytes())

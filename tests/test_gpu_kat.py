@@ -12,7 +12,7 @@ import kat_cases as K
 
 A, B = 7, 9                                                  # two function indices
 EMPTY = 20 ** 8 + 1                                          # whichKmer > MAX_ENCODED: empty slot (KGJ:1000)
-STRATEGIES = ["direct", "partitioned", "partitioned2"]
+STRATEGIES = ["direct", "partitioned", "partitioned_tags"]
 # one codon per residue, standard code (KGJ:88-93), written out here so that the DNA cases do not lean on synth.back_translate
 CODON = {"A": "GCT", "C": "TGT", "D": "GAT", "E": "GAA", "F": "TTT", "G": "GGT", "H": "CAT", "I": "ATT", "K": "AAA", "L": "CTG",
          "M": "ATG", "N": "AAT", "P": "CCT", "Q": "CAA", "R": "CGT", "S": "TCT", "T": "ACT", "V": "GTT", "W": "TGG", "Y": "TAT"}
@@ -22,7 +22,7 @@ K1 = {"AAAAAAAA": 0, "ACDEFGHI": 70914127, "MKLVTGAS": 13343650015, "YYYYYYYY": 
 
 def _strategy(monkeypatch, strategy):
     monkeypatch.setenv("KG_PARTITION", "0" if strategy == "direct" else "1")
-    monkeypatch.setenv("KG_PART_LEVELS", "2" if strategy == "partitioned2" else "1")
+    monkeypatch.setenv("KG_BIDX", "0" if strategy == "partitioned_tags" else "1")
 
 
 def _image(n, entries, extra=b""):
@@ -222,12 +222,11 @@ def test_aggregation_cases_through_kg_aggregate_hits(make):
         assert otu == want_otu, (name, otu)
 
 
-@pytest.mark.parametrize("strategy", ["direct", "partitioned", "partitioned2"])
+@pytest.mark.parametrize("strategy", STRATEGIES)
 @pytest.mark.parametrize("make", K.LOOKUP_CASES, ids=lambda f: f.__name__)
 def test_lookup_cases_through_kg_scan(make, strategy, monkeypatch):
     from kmergutsjava_amd import hotpath
-    monkeypatch.setenv("KG_PARTITION", "0" if strategy == "direct" else "1")
-    monkeypatch.setenv("KG_PART_LEVELS", "2" if strategy == "partitioned2" else "1")
+    _strategy(monkeypatch, strategy)
     for name, img, q, want in make():
         with hotpath.SignatureTable.from_bytes(img) as tab, tab.scan(q, np.array([0, len(q)]), hotpath.Params(aa=True, min_hits=2)) as r:
             got = [(int(h["from0InProt"]), int(h["oI"]), int(h["avgOffFromEnd"]), int(h["fI"]), float(h["functionWt"]))

@@ -12,20 +12,15 @@ from helpers import assert_same_records, plant
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["direct", "partitioned", "partitioned_tags", "partitioned2"])
+@pytest.fixture(autouse=True, params=["direct", "partitioned", "partitioned_tags"])
 def strategy(request, monkeypatch):
     """Every parity test runs with the scan strategies: direct probing; partitioned probing (KG_PARTITION=1 forces the
     bucketed path even on tables small enough for the direct one) -- the byte home index probed in the L2 by scans without
-    KG_F_COUNTERS, the tags by scans with them; the same with the index switched off (KG_BIDX=0: tags for every scan); and
-    the second partition level (KG_PART_LEVELS=2: sub-scatter + tags probed in LDS; 2^9-slot sub-buckets so that the small
-    test tables have several per bucket).
+    KG_F_COUNTERS, the tags by scans with them; and the same with the index switched off (KG_BIDX=0: tags for every scan).
     Most workloads here scan with counters (they compare them with the oracle's), which the index path does not serve: under
     "partitioned" every such scan is therefore REPEATED without counters -- the index path -- and its records, event bytes and
     flags must be the ones of the scan the test goes on to compare with the oracle."""
     monkeypatch.setenv("KG_PARTITION", "0" if request.param == "direct" else "1")
-    monkeypatch.setenv("KG_PART_LEVELS", "2" if request.param == "partitioned2" else "1")
-    if request.param == "partitioned2":
-        monkeypatch.setenv("KG_PART_SUBSHIFT", "9")
     if request.param == "partitioned_tags":
         monkeypatch.setenv("KG_BIDX", "0")
     if request.param == "partitioned":
