@@ -68,6 +68,11 @@ typedef struct kg_params {
 
 #define KG_F_COUNTERS        1u  /* also count windows_valid / slots_inspected, slower     */
 #define KG_F_SKIP_AGGREGATE  2u  /* stop after the hit records (no CALL / OTU stage)                   */
+#define KG_F_PROGRESS        4u  /* also record what the reference's table stream would have reported  */
+                                 /* (kg_result_progress, kg_result_hit_slots): the "Processed: NN%"    */
+                                 /* lines of KGJ:1016-1025 and where a short table file fails,          */
+                                 /* KGJ:985-988 / 1036-1049.  Runs the walking kernels of KG_F_COUNTERS */
+                                 /* (the stats' counters are filled too); tables of < 2^32 records      */
 
 /* Event byte per hit record (kg_result_hit_events) and per container (kg_result_container_tail_events):
  * what gatherHits (KGJ:457-514) did at that record, so that a host can print the -d stream (HIT, after-hit,
@@ -143,6 +148,26 @@ typedef struct kg_stats {
                                  /* default).  (2 and 3 were round 3's second partition level, removed in round 4.)                 */
 } kg_stats;
 
+/* KG_F_PROGRESS: the slots the reference's merge-join (KGJ:959-1029) visits = the slots some query's walk reads, summed up
+ * the way its progress lines and its failure modes need them.  The join runs in slot order and prints
+ *     "Processed: <10 f>%, time=<ms> ms., found-so-far=<k-mers found at slots <= s>"
+ * at every visited slot s whose tenth f = (int)(10.0 * ((double)(s + 1) / (double)numSigs)) differs from the last one printed
+ * (KGJ:1017-1024), i.e. once per tenth, at the first slot visited in it. */
+typedef struct kg_progress {
+    int64_t first_visited[11];   /* [f]: the first slot visited in tenth f, -1 when none (f = 10: the slot numSigs - 1 and, for   */
+                                 /* a table file longer than numSigs records, everything behind it)                               */
+    int64_t last_visited;        /* the last slot visited, -1 when none                                                           */
+    int64_t first_beyond;        /* the smallest home slot of a query k-mer at or behind the END of the record stream (a table    */
+                                 /* file shorter than numSigs records), -1 when none: the join has to skip to it and fails --     */
+                                 /* "Error skipping <24 x (first_beyond - last_visited - 1)> bytes" on a .gz stream               */
+                                 /* (KGJ:1036-1049), EOFException ("Error: null") on a plain file or when nothing is skipped      */
+    int64_t walk_ran_off;        /* 1: a walk reached the end of the stream undecided: EOFException before any such skip          */
+    int64_t stream_slots;        /* records in the table stream (numSigs for a complete file)                                     */
+    int64_t found_upto[11];      /* [f]: distinct k-mers found at slots <= first_visited[f] = the line's found-so-far (0 when the */
+                                 /* tenth was not visited)                                                                        */
+    int64_t kmers_found;         /* distinct k-mers found by this scan = the reference's kmersFound (KGJ:1004-1006, 1031-1033)     */
+} kg_progress;
+
 typedef struct kg_table  kg_table;
 typedef struct kg_result kg_result;
 
@@ -200,6 +225,12 @@ const uint8_t *kg_result_container_tail_events(kg_result *r);/* n_containers byt
 /* hits[first .. first + count) straight into caller-owned memory (e.g. a JNA Memory / numpy array); pageable
  * destinations are fed through the library's cached pinned blocks, the copy overlapped with the transfer. */
 int kg_result_copy_hits(kg_result *r, int64_t first, int64_t count, kg_hit *dst);
+/* KG_F_PROGRESS scans only (NULL / KG_ERR_ARG otherwise): the table slot every hit record was found at (n_hits entries,
+ * parallel to kg_result_hits: distinct slots = distinct k-mers found, the reference's kmersFound, KGJ:1004-1006), and the
+ * summary above.  Several scans of one run (batches): the slots combine by minimum / maximum; the two counts are per scan (a
+ * k-mer found in two batches counts in both), a front end that needs them over several scans counts the distinct hit slots. */
+const uint32_t *kg_result_hit_slots(kg_result *r);
+int kg_result_progress(const kg_result *r, kg_progress *out);
 /* Device views (valid until kg_result_free) for callers that keep working in HBM. */
 const void    *kg_result_device_hits(const kg_result *r);
 const void    *kg_result_device_calls(const kg_result *r);

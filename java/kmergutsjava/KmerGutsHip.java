@@ -28,6 +28,7 @@ public interface KmerGutsHip extends Library {
         KG_ERR_LIMIT = -7, KG_ERR_BUSY = -8;
     int KG_F_COUNTERS = 1;
     int KG_F_SKIP_AGGREGATE = 2;
+    int KG_F_PROGRESS = 4;
 
     /** struct kg_params: the instance fields the hot path reads (KmerGutsJava.java:102-106). */
     class KgParams extends Structure {
@@ -50,6 +51,18 @@ public interface KmerGutsHip extends Library {
                     "windows_valid", "slots_inspected", "table_bytes", "ms_scan", "ms_order", "ms_aggregate",
                     "ms_total", "scan_launches", "partitioned", "ms_part_scatter", "ms_part_tag", "ms_part_verify", "fallback",
                     "part_chunks", "part_buckets", "part_shift", "lookup_ran_off", "agg_pieces", "part_levels"});
+        }
+    }
+
+    /** struct kg_progress (KG_F_PROGRESS scans): what lookup's table stream reports and where it fails (KmerGutsJava.java:1016-1049). */
+    class KgProgress extends Structure {
+        public long[] first_visited = new long[11];
+        public long last_visited, first_beyond, walk_ran_off, stream_slots;
+        public long[] found_upto = new long[11];
+        public long kmers_found;
+        public KgProgress() {
+            setFieldOrder(new String[] {"first_visited", "last_visited", "first_beyond", "walk_ran_off", "stream_slots", "found_upto",
+                    "kmers_found"});
         }
     }
 
@@ -81,6 +94,8 @@ public interface KmerGutsHip extends Library {
     Pointer kg_result_device_hits(Pointer result);
     Pointer kg_result_device_calls(Pointer result);
     int kg_result_copy_hits(Pointer result, long first, long count, Pointer dst);
+    Pointer kg_result_hit_slots(Pointer result);             // uint32[n_hits]      KG_F_PROGRESS scans
+    int kg_result_progress(Pointer result, KgProgress out);
     Pointer kg_result_device_otu(Pointer result);
     Pointer kg_result_device_container_hit_start(Pointer result);
     Pointer kg_result_device_container_call_start(Pointer result);

@@ -18,6 +18,7 @@ KG_ERR_NOMEM = -5
 KG_ERR_BUSY = -8
 KG_F_COUNTERS = 1
 KG_F_SKIP_AGGREGATE = 2
+KG_F_PROGRESS = 4
 KG_OI_BUFSZ = 5
 
 # every symbol include/kmerguts_hip.h declares
@@ -25,7 +26,7 @@ EXPORTS = (
     "kg_table_open", "kg_table_from_memory", "kg_table_from_device", "kg_table_info", "kg_table_live_device_bytes", "kg_table_close",
     "kg_scan", "kg_scan_device", "kg_aggregate_hits", "kg_process_set_of_hits", "kg_result_stats", "kg_result_hits", "kg_result_container_hit_start",
     "kg_result_calls", "kg_result_container_call_start", "kg_result_otu", "kg_result_hit_events",
-    "kg_result_container_tail_events", "kg_result_copy_hits", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu",
+    "kg_result_container_tail_events", "kg_result_copy_hits", "kg_result_hit_slots", "kg_result_progress", "kg_result_device_hits", "kg_result_device_calls", "kg_result_device_otu",
     "kg_result_device_container_hit_start", "kg_result_device_container_call_start", "kg_result_free", "kg_restore_hits_device",
     "kg_last_error", "kg_version",
 )
@@ -61,6 +62,17 @@ class KgStats(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
+
+
+class KgProgress(C.Structure):
+    """struct kg_progress (KG_F_PROGRESS scans): what the reference's table stream would have reported (KGJ:1016-1049)."""
+    _fields_ = [("first_visited", C.c_int64 * 11), ("last_visited", C.c_int64), ("first_beyond", C.c_int64),
+                ("walk_ran_off", C.c_int64), ("stream_slots", C.c_int64), ("found_upto", C.c_int64 * 11), ("kmers_found", C.c_int64)]
+
+    def as_dict(self):
+        return {"first_visited": [int(x) for x in self.first_visited], "last_visited": int(self.last_visited),
+                "first_beyond": int(self.first_beyond), "walk_ran_off": int(self.walk_ran_off), "stream_slots": int(self.stream_slots),
+                "found_upto": [int(x) for x in self.found_upto], "kmers_found": int(self.kmers_found)}
 
 
 class KmerGutsNativeError(RuntimeError):
@@ -114,6 +126,9 @@ def load() -> C.CDLL:
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = vp
     lib.kg_result_copy_hits.argtypes = [vp, C.c_int64, C.c_int64, vp]
+    lib.kg_result_hit_slots.argtypes = [vp]
+    lib.kg_result_hit_slots.restype = vp
+    lib.kg_result_progress.argtypes = [vp, C.POINTER(KgProgress)]
     lib.kg_restore_hits_device.argtypes = [C.c_int, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp]
     lib.kg_result_free.argtypes = [vp]
     lib.kg_result_free.restype = None

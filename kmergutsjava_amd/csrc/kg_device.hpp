@@ -539,6 +539,78 @@ __device__ __forceinline__ void row_record_key(const BlockDesc &bd, int r, int l
 }
 
 // ---------------------------------------------------------------------------------------
+// KG_F_PROGRESS: what the reference's table stream reports while its merge-join runs (KGJ:1016-1025: a "Processed: NN%" line
+// whenever the tenth of the table changes -- at slots the join VISITS, i.e. slots some query's walk reads) and where it fails on
+// a table file shorter than numSigs records (KGJ:985-988, 1036-1049).  The walking kernels note every query's walk
+// [home slot, last slot read] here; the host turns it into the lines (kmer_guts_java.py, kmer_guts_cli.cpp).
+struct Progress {
+    unsigned long long first[11];     // first[d]: smallest slot visited in tenth d (~0: none); tenth of slot s = bounds below
+    unsigned long long last_plus1;    // 1 + the largest slot visited (0: none)
+    unsigned long long first_beyond;  // smallest home slot >= limit among the query k-mers (~0: none): the stream ends before it
+    unsigned long long walk_ran_off;  // 1: some walk reached the end of the record stream undecided (EOFException, KGJ:1097-1126)
+    unsigned long long lo[11];        // lo[d]: smallest slot whose tenth is >= d (host-computed with the reference's double
+                                      // arithmetic, KGJ:1018); lo[0] = 0, ~0 when no slot reaches d
+    unsigned long long found_upto[11];// distinct k-mers found at slots <= first[d] (count_found_kernel): "found-so-far"
+    unsigned long long kmers_found;   // distinct k-mers found = distinct slots among the hit records (KGJ:1004-1006)
+};
+
+// kmersFound: a k-mer counts once however many query positions carry it (KGJ:1004-1015), and a k-mer is found at one slot:
+// the distinct slots of the hit records, marked in a bitmap over the table's slots and counted up to each tenth's first
+// visited slot.
+__global__ void mark_found_kernel(const uint32_t *__restrict__ slots, uint64_t n, uint32_t *bitmap)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t s = slots[i];
+        atomicOr(&bitmap[s >> 5], 1u << (s & 31u));
+    }
+}
+__global__ void count_found_kernel(const uint32_t *__restrict__ bitmap, uint64_t n_words, Progress *p)
+{
+    unsigned long long upto[11], all = 0;
+    for (int f = 0; f <= 10; f++) upto[f] = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        const uint32_t bits = bitmap[w];
+        if (!bits) continue;
+        all += (unsigned long long)__popc(bits);
+        const uint64_t b = w << 5;
+        for (int f = 0; f <= 10; f++) {
+            const unsigned long long t = p->first[f];                 // ~0: tenth not visited (its count is not used)
+            if (t == ~0ull || t < b) continue;
+            const uint64_t k = t - b;                                  // bits 0..k count
+            upto[f] += (unsigned long long)__popc(k >= 31 ? bits : bits & ((2u << k) - 1u));
+        }
+    }
+    for (int f = 0; f <= 10; f++) {
+        for (int off = 32; off > 0; off >>= 1) upto[f] += __shfl_down(upto[f], off);
+        if ((threadIdx.x & 63) == 0 && upto[f]) atomicAdd(&p->found_upto[f], upto[f]);
+    }
+    for (int off = 32; off > 0; off >>= 1) all += __shfl_down(all, off);
+    if ((threadIdx.x & 63) == 0 && all) atomicAdd(&p->kmers_found, all);
+}
+
+// One query's walk started at its home slot and stopped at `stop`: the slot of its k-mer or of the first empty record, or
+// >= limit when it reached the end of the stream undecided; it read the slots home .. min(stop, limit - 1).  Reads first,
+// atomics only for a new minimum / maximum: after the first few walks of a tenth nearly every walk leaves the words alone.
+__device__ __forceinline__ void progress_note_walk(Progress *p, uint64_t home, uint64_t stop, uint64_t limit)
+{
+    const uint64_t last = stop < limit ? stop : limit - 1;
+    if (stop >= limit) p->walk_ran_off = 1ull;
+    int d = 0;
+#pragma unroll
+    for (int k = 1; k <= 10; k++) d += p->lo[k] <= home ? 1 : 0;
+    if (home < *const_cast<volatile unsigned long long *>(&p->first[d])) atomicMin(&p->first[d], (unsigned long long)home);
+    for (int k = d + 1; k <= 10 && p->lo[k] <= last; k++)                       // the walk crosses into tenth k at lo[k]
+        if (p->lo[k] < *const_cast<volatile unsigned long long *>(&p->first[k])) atomicMin(&p->first[k], p->lo[k]);
+    if (last + 1 > *const_cast<volatile unsigned long long *>(&p->last_plus1)) atomicMax(&p->last_plus1, (unsigned long long)(last + 1));
+}
+__device__ __forceinline__ void progress_note_beyond(Progress *p, uint64_t home)
+{
+    if (home < *const_cast<volatile unsigned long long *>(&p->first_beyond)) atomicMin(&p->first_beyond, (unsigned long long)home);
+}
+
+// ---------------------------------------------------------------------------------------
 // Probe N independent query k-mers per lane (KGJ:944-1034 semantics: from the home slot forward until the
 // k-mer, an empty slot or the end of the stream; never wrap).  16 tags per load, records touched only on a
 // fingerprint match; the rare longer walks share one copy of the generic walk, rows picked by register muxes.
@@ -550,7 +622,9 @@ __device__ __forceinline__ void row_record_key(const BlockDesc &bd, int r, int l
 template <int N, bool COUNTERS>
 __device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t (&val)[N], const uint64_t (&home_in)[N],
                                             const uint32_t (&fp)[N], bool (&valid)[N], Payload (&ent)[N],
-                                            unsigned long long &ctr_valid, unsigned long long &ctr_slots, bool &ran_off)
+                                            unsigned long long &ctr_valid, unsigned long long &ctr_slots, bool &ran_off,
+                                            Progress *prog = nullptr /* COUNTERS only: note the walks (KG_F_PROGRESS) */,
+                                            uint32_t *found_slot = nullptr /* COUNTERS only: [N], the slot a found query was found at */)
 {
     uint64_t cand[N];     // slot under examination
     uint32_t skip[N];
@@ -560,7 +634,7 @@ __device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t
     for (int q = 0; q < N; q++) {
         cand[q] = home_in[q];
         if (COUNTERS) { home[q] = cand[q]; if (valid[q]) ctr_valid++; }   // query k-mers (KGJ:913-920)
-        if (valid[q] && cand[q] >= tab.limit) ran_off = true;
+        if (valid[q] && cand[q] >= tab.limit) { ran_off = true; if (COUNTERS && prog) progress_note_beyond(prog, cand[q]); }
         valid[q] = valid[q] && cand[q] < tab.limit;     // beyond the stream: EOF, not found, nothing inspected
         cand[q] = probe_window(cand[q], &skip[q]);
         if (valid[q]) tg[q] = load_tags(tab.tags + cand[q]);
@@ -642,6 +716,8 @@ __device__ __forceinline__ uint32_t probe_n(const TableView &tab, const uint64_t
             if (valid[q]) {
                 uint64_t last = stop[q] < tab.limit ? stop[q] + 1 : tab.limit;
                 ctr_slots += last - home[q];
+                if (prog) progress_note_walk(prog, home[q], stop[q], tab.limit);
+                if (found_slot) found_slot[q] = (uint32_t)stop[q];
             }
         }
     }
@@ -687,7 +763,8 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
     uint32_t m35, const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t n_blocks,
     uint32_t *__restrict__ counts,
     uint32_t *__restrict__ block_stage_base, kg_hit *__restrict__ stage, unsigned long long *cursor, uint64_t stage_cap,
-    uint32_t stage_chunk, unsigned long long *ctr)
+    uint32_t stage_chunk, unsigned long long *ctr,
+    Progress *prog /* KG_F_PROGRESS (COUNTERS kernels), else null */, uint32_t *__restrict__ stage_slot /* likewise: parallel to stage[] */)
 {
     constexpr int ROWS = AA ? 1 : 6;
     constexpr int NG = ROWS / RPG;
@@ -729,7 +806,11 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
             }
 
             Payload ent[RPG];
-            const uint32_t foundm = probe_n<RPG, COUNTERS>(tab, val, home, fp, valid, ent, ctr_valid, ctr_slots, ran_off);
+            uint32_t fslot[RPG];
+#pragma unroll
+            for (int q = 0; q < RPG; q++) fslot[q] = 0;
+            const uint32_t foundm = probe_n<RPG, COUNTERS>(tab, val, home, fp, valid, ent, ctr_valid, ctr_slots, ran_off,
+                                                           COUNTERS ? prog : nullptr, COUNTERS && stage_slot ? fslot : nullptr);
 
             // ---- ordered compaction: ballot per row, staging records handed out from the wave's reservation
             uint32_t cnt[RPG], rank[RPG];
@@ -766,6 +847,7 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
                         row_record_key<AA>(bd, g * RPG + q, lane, &h.container, &h.from0InProt);
                         h.oI = ent[q].oI; h.avgOffFromEnd = ent[q].avg; h.fI = ent[q].fI; h.functionWt = ent[q].wt;
                         stage[base + rowbase + rank[q]] = h;
+                        if (COUNTERS && stage_slot) stage_slot[base + rowbase + rank[q]] = fslot[q];
                     }
                     rowbase += cnt[q];
                 }
@@ -903,7 +985,8 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void place_kernel(const BlockDe
                                                                   const uint32_t *__restrict__ counts,
                                                                   const uint32_t *__restrict__ offs,
                                                                   const uint32_t *__restrict__ block_stage_base, uint32_t rpg,
-                                                                  const kg_hit *__restrict__ stage, kg_hit *__restrict__ hits)
+                                                                  const kg_hit *__restrict__ stage, kg_hit *__restrict__ hits,
+                                                                  const uint32_t *__restrict__ stage_slot, uint32_t *__restrict__ hit_slots)
 {
     constexpr int ROWS = AA ? 1 : 6;
     const int lane = threadIdx.x & 63;
@@ -917,7 +1000,10 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void place_kernel(const BlockDe
         if ((uint32_t)r % rpg == 0) src = block_stage_base[(uint64_t)it * ng + (uint32_t)r / rpg];
         const uint32_t vrow = row_index<AA>(bd, it, r);
         uint32_t n = counts[vrow];
-        if ((uint32_t)lane < n) hits[(uint64_t)offs[vrow] + lane] = stage[(uint64_t)src + lane];
+        if ((uint32_t)lane < n) {
+            hits[(uint64_t)offs[vrow] + lane] = stage[(uint64_t)src + lane];
+            if (hit_slots) hit_slots[(uint64_t)offs[vrow] + lane] = stage_slot[(uint64_t)src + lane];      // KG_F_PROGRESS
+        }
         src += n;
     }
 }

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(kHThreads) void group_place_kernel(const kg_hit *__
                                                                 uint32_t g0, uint32_t gshift, uint32_t row_lo, uint32_t row_hi /* the chunk's rows */,
                                                                 const RowGeo *__restrict__ geo, uint64_t n_rows_all, uint32_t staged,
                                                                 const uint64_t *__restrict__ base,
-                                                                kg_hit *__restrict__ hits, uint64_t hits_cap, uint32_t *__restrict__ offs)
+                                                                kg_hit *__restrict__ hits, uint64_t hits_cap, uint32_t *__restrict__ offs,
+                                                                uint32_t *__restrict__ hit_slots /* KG_F_PROGRESS: parallel to hits[], else null */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char p_lds[];
     const uint32_t R = 1u << gshift;
@@ -349,6 +350,8 @@ __global__ __launch_bounds__(kHThreads) void group_place_kernel(const kg_hit *__
             const uint32_t key = h.container, rl = (key >> 6) & (R - 1u), ol = key & 63u;
             const RowGeo gr = staged ? lgeo[rl] : geo[key >> 6];
             const uint32_t rank = pre[rl] + (uint32_t)__popcll(masks[rl] & ((1ull << ol) - 1ull));      // inside the group
+            if (hit_slots && chunk_base + lo + rank < hits_cap)
+                hit_slots[chunk_base + lo + rank] = (uint32_t)h.from0InProt;      // the verify pass left the found slot there
             h.container = gr.container;
             h.from0InProt = gr.pos_first + (int32_t)ol;
             if (to_lds) {

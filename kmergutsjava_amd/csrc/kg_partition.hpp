@@ -138,7 +138,8 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
     const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, uint32_t block_lo, uint32_t n_blocks /* of this launch */,
     uint64_t limit, uint32_t num_sigs /* 64 <= num_sigs < 2^31 */, uint32_t m35, uint32_t shift, uint32_t n_buckets, uint32_t cap,
     uint64_t *__restrict__ ent, uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap, uint32_t *__restrict__ ovf_bucket,
-    uint64_t *__restrict__ ovf_ent, uint32_t *lowc_cursor /* [0] count */, uint32_t *__restrict__ lowc_blocks, unsigned long long *ctr)
+    uint64_t *__restrict__ ovf_ent, uint32_t *lowc_cursor /* [0] count */, uint32_t *__restrict__ lowc_blocks, unsigned long long *ctr,
+    Progress *prog /* KG_F_PROGRESS, else null */)
 {
     constexpr int ROWS = AA ? 1 : 6;
     typedef typename WaveLds<AA>::type Enc;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
                 bool valid = row_halves<AA>(l, r, lane, bd, &hi, &lo);
                 const uint32_t slot = split_fast(hi, lo, num_sigs, m35, &q);
                 if (valid) vmask |= 1u << k;                            // query k-mers (KGJ:913-920), counted per block below
-                if (valid && slot >= limit32) ran_off = true;           // (truncated table file)
+                if (valid && slot >= limit32) { ran_off = true; if (prog) progress_note_beyond(prog, slot); }   // (truncated table file)
                 valid = valid && slot < limit32;                        // beyond the stream: never probed
                 bk[k] = slot >> shift;
                 const uint32_t low = (q << shift) | (slot & ((1u << shift) - 1u));
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(64 * kLowcWaves) void lowc_blocks_kernel(
     const uint8_t *__restrict__ seq, const BlockDesc *__restrict__ blocks, const uint32_t *__restrict__ lowc_cursor,
     const uint32_t *__restrict__ lowc_blocks, uint64_t limit, uint32_t num_sigs, uint32_t m35, uint32_t shift, uint32_t n_regions,
     uint32_t cap, uint64_t *__restrict__ ent, uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap,
-    uint32_t *__restrict__ ovf_bucket, uint64_t *__restrict__ ovf_ent, unsigned long long *ctr)
+    uint32_t *__restrict__ ovf_bucket, uint64_t *__restrict__ ovf_ent, unsigned long long *ctr, Progress *prog)
 {
     constexpr int ROWS = AA ? 1 : 6;
     __shared__ typename WaveLds<AA>::type lds[kLowcWaves];
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(64 * kLowcWaves) void lowc_blocks_kernel(
             bool valid = row_halves<AA>(l, r, lane, bd, &hi, &lo);
             const uint32_t slot = split_fast(hi, lo, num_sigs, m35, &q);
             if (valid) n_valid++;
-            if (valid && slot >= limit32) ran_off = true;
+            if (valid && slot >= limit32) { ran_off = true; if (prog) progress_note_beyond(prog, slot); }
             bool pend = valid && slot < limit32;
             const uint32_t bkt = slot >> shift;
             const uint64_t e = ((uint64_t)window_key<AA>(bd, it, r, lane) << 32) | ((q << shift) | (slot & ((1u << shift) - 1u)));
@@ -543,7 +544,7 @@ template <bool AA, int N, bool COUNTERS>
 __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, uint32_t shift, const uint64_t (&e)[N],
                                               kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used,
                                               unsigned long long *cursor, uint64_t ulist_cap, UListState &u,
-                                              unsigned long long &ctr_slots, bool &ran_off, int lane)
+                                              unsigned long long &ctr_slots, bool &ran_off, int lane, Progress *prog)
 {
     uint64_t val[N], slot[N];
     bool valid[N];
@@ -559,7 +560,11 @@ __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, 
     }
     Payload pay[N];
     unsigned long long ctr_dummy = 0;
-    const uint32_t foundm = probe_n<N, COUNTERS>(tab, val, slot, fp, valid, pay, ctr_dummy, ctr_slots, ran_off);
+    uint32_t fslot[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) fslot[k] = 0;
+    const uint32_t foundm = probe_n<N, COUNTERS>(tab, val, slot, fp, valid, pay, ctr_dummy, ctr_slots, ran_off, COUNTERS ? prog : nullptr,
+                                                 COUNTERS ? fslot : nullptr);
     uint32_t cnt[N], rank[N], total = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -585,7 +590,7 @@ __device__ __forceinline__ void probe_entries(const TableView &tab, uint32_t b, 
                 if ((foundm >> k) & 1u) {
                     kg_hit h;
                     h.container = id[k];
-                    h.from0InProt = 0;
+                    h.from0InProt = (int32_t)fslot[k];       // (the slot it was found at, for KG_F_PROGRESS; the placement overwrites it)
                     h.oI = pay[k].oI; h.avgOffFromEnd = pay[k].avg; h.fI = pay[k].fI; h.functionWt = pay[k].wt;
                     ulist[u.base + at + rank[k]] = h;
                 }
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
     uint32_t grab /* entry slots per hand-out, multiple of 256 * kProbeN */,
     uint32_t *next_region /* ticket counter of group x at [32 * x], zeroed */,
     CandRec *__restrict__ cand, uint32_t *__restrict__ cand_used, unsigned long long *cand_cursor, uint64_t cand_cap,
-    unsigned long long *ctr)
+    unsigned long long *ctr, Progress *prog /* KG_F_PROGRESS (COUNTERS kernel), else null */)
 {
     constexpr int N = kProbeN;
     const uint32_t lim32 = (uint32_t)limit;
@@ -729,7 +734,10 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_tag_kernel(
                     else {
                         const uint32_t home = bbase | (low[k] & smask), at = home + walked[k];
                         if (at >= lim32) ran_off = true;       // the "empty slot" is the padding behind the last record
-                        if (COUNTERS) ctr_slots += (at < lim32 ? at + 1u : lim32) - home;
+                        if (COUNTERS) {
+                            ctr_slots += (at < lim32 ? at + 1u : lim32) - home;
+                            if (prog) progress_note_walk(prog, home, at, lim32);
+                        }
                     }
                 }
             }
@@ -929,7 +937,7 @@ __global__ __launch_bounds__(256) void verify_kernel(
     const uint8_t *__restrict__ entries, const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, uint64_t magic,
     const CandRec *__restrict__ cand, const uint32_t *__restrict__ cand_used, const unsigned long long *cand_cursor,
     uint64_t cand_cap, kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used, unsigned long long *cursor,
-    uint64_t ulist_cap, unsigned long long *ctr)
+    uint64_t ulist_cap, unsigned long long *ctr, Progress *prog /* KG_F_PROGRESS (COUNTERS kernels), else null */)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -992,7 +1000,10 @@ __global__ __launch_bounds__(256) void verify_kernel(
                     if (found) { e = load_entry(tab, s); break; }
                     s += 3;
                 }
-                if (COUNTERS) ctr_slots += (s < limit ? s + 1 : limit) - home;
+                if (COUNTERS) {
+                    ctr_slots += (s < limit ? s + 1 : limit) - home;
+                    if (prog) progress_note_walk(prog, home, s, limit);
+                }
             } else if (act) {
                 if (!(r.walked & kWalkOn)) {               // a fingerprint match at s: check the record
                     e = load_entry(tab, s);
@@ -1014,7 +1025,10 @@ __global__ __launch_bounds__(256) void verify_kernel(
                         s += 1;
                     }
                 }
-                if (COUNTERS) ctr_slots += (s < limit ? s + 1 : limit) - home;
+                if (COUNTERS) {
+                    ctr_slots += (s < limit ? s + 1 : limit) - home;
+                    if (prog) progress_note_walk(prog, home, s, limit);
+                }
             }
             const unsigned long long m = __ballot(found);
             const uint32_t total = (uint32_t)__popcll(m);
@@ -1023,7 +1037,7 @@ __global__ __launch_bounds__(256) void verify_kernel(
                 if (at != ~0ull && found) {
                     kg_hit h;
                     h.container = r.id;
-                    h.from0InProt = 0;
+                    h.from0InProt = (int32_t)(uint32_t)s;    // (the slot it was found at, for KG_F_PROGRESS; the placement overwrites it)
                     h.oI = e.oI; h.avgOffFromEnd = e.avg; h.fI = e.fI; h.functionWt = e.wt;
                     stream_store_hit(ulist + at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), h);
                 }
@@ -1044,7 +1058,7 @@ __global__ __launch_bounds__(256) void overflow_probe_kernel(
     const uint8_t *__restrict__ entries, const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, uint64_t magic,
     const uint32_t *__restrict__ ovf_bucket, const uint64_t *__restrict__ ovf_ent, const uint32_t *__restrict__ ovf_cursor,
     uint32_t ovf_cap, uint32_t shift, kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used, unsigned long long *cursor, uint64_t ulist_cap,
-    unsigned long long *ctr)
+    unsigned long long *ctr, Progress *prog)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1060,7 +1074,7 @@ __global__ __launch_bounds__(256) void overflow_probe_kernel(
         const uint32_t b = ovf_bucket[g];
         uint64_t e[1];
         e[0] = lane < (int)kGroup ? ovf_ent[(uint64_t)g * kGroup + lane] : kEntInvalid;
-        probe_entries<AA, 1, COUNTERS>(tab, b, shift, e, ulist, chunk_used, cursor, ulist_cap, u, ctr_slots, ran_off, lane);
+        probe_entries<AA, 1, COUNTERS>(tab, b, shift, e, ulist, chunk_used, cursor, ulist_cap, u, ctr_slots, ran_off, lane, prog);
     }
     if (lane == 0 && u.have && u.base + kUChunk <= ulist_cap) chunk_used[u.base / kUChunk] = u.used;
     flush_ran_off(ran_off, ctr, lane);

@@ -17,6 +17,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdint>
@@ -27,7 +28,6 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
-#include <unordered_set>
 #include <vector>
 
 #include "../../include/kmerguts_hip.h"
@@ -374,32 +374,6 @@ long long now_ms()
 
 }  // namespace
 
-// encodedKmer (KGJ:274-292) of the window behind a hit record: container f of a sequence (protein: f = 0; DNA: + 0 1 2,
-// - 0 1 2, KGJ:1064-1072), residue index pos.  Host side, for the -d line "Kmers found" only.
-static int64_t kmer_value_at(const uint8_t *s, int64_t len, bool aa, int f, int32_t pos)
-{
-    static const char *alpha = "ACDEFGHIKLMNPQRSTVWY";
-    static const char *code = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
-    auto aa_of = [&](char c) -> int64_t { const char *q = strchr(alpha, c); return (q && c) ? q - alpha : 20; };
-    auto base = [](uint8_t c) -> int { switch (c) { case 'a': case 'A': return 0; case 'c': case 'C': return 1;
-                                                     case 'g': case 'G': return 2; case 't': case 'T': case 'u': case 'U': return 3;
-                                                     default: return 4; } };
-    int64_t v = 0;
-    for (int j = 0; j < 8; j++) {
-        int64_t c;
-        if (aa) c = aa_of((char)s[pos + j]);
-        else {
-            int b[3];
-            for (int t = 0; t < 3; t++) {
-                const int64_t k = (f % 3) + 3 * ((int64_t)pos + j) + t;             // base index on the window's strand
-                b[t] = f < 3 ? base(s[k]) : 3 - base(s[len - 1 - k]);                // revComp (KGJ:263-272)
-            }
-            c = (b[0] | b[1] | b[2]) > 3 || b[0] < 0 || b[1] < 0 || b[2] < 0 ? 20 : aa_of(code[b[0] * 16 + b[1] * 4 + b[2]]);
-        }
-        v = v * 20 + c;
-    }
-    return v;
-}
 
 #ifndef KG_CLI_NO_MAIN
 int main(int argc, char **argv)
@@ -460,22 +434,24 @@ int main(int argc, char **argv)
             out.put("Kmer-table info: numSigs=" + std::to_string(ns) + ", entrySize=" + std::to_string(es) +
                     ", version=" + std::to_string(ver) + "\n");
         }
-        bool error_reported = false;
         kg_params p{};
         p.aa = o.aa; p.order_constraint = o.order_constraint; p.min_hits = o.min_hits;
         p.min_weighted_hits = o.min_weighted_hits; p.max_gap = o.max_gap; p.flags = 0;
         const int per = o.aa ? 1 : 6;
-        const int64_t kMaxBatchChars = 1500000000ll;               // below the ABI's 2^32-256 windows per call
-        if (o.debug) {
-            // KGJ:1031-1033 "Kmers found: N (pos-count=M)": N = distinct matched k-mer values, M = hit records, over
-            // EVERY FASTA record (the reference's lookup fills the containers of records that a later record of the
-            // same id shadows in the report too, KGJ:805-809).  The line precedes the report, so -d scans the records
-            // once more here, hit records only; a hit record does not carry its k-mer: recomputed from the characters.
+        // KG_CLI_BATCH_CHARS: test hook (smaller batches)
+        const int64_t kMaxBatchChars = getenv("KG_CLI_BATCH_CHARS") ? std::max(1ll, atoll(getenv("KG_CLI_BATCH_CHARS"))) : 1500000000ll;   // below the ABI's 2^32-256 windows per call
+        if (o.debug || !to_stdout) {
+            // What lookup prints besides the records -- "Processed: NN%, time=..., found-so-far=K" once per tenth of the table
+            // the merge-join visits (KGJ:1016-1025), with -d "Kmers found: N (pos-count=M)" (KGJ:1031-1033) -- and how run()
+            // reports the stream's failure (KGJ:797-802).  All of it is about EVERY FASTA record (the reference's lookup fills the
+            // containers of records that a later record of the same id shadows in the report too, KGJ:805-809) and precedes
+            // the report, so the records are scanned once more here, hit records only, with KG_F_PROGRESS: the library notes
+            // which table slots the reference's stream would have visited and counts the distinct k-mers found.
             kg_params pc = p;
-            pc.flags = KG_F_SKIP_AGGREGATE;
-            std::unordered_set<int64_t> distinct;
+            pc.flags = KG_F_SKIP_AGGREGATE | KG_F_PROGRESS;
             long long pos_count = 0;
-            bool ran_off = false;
+            std::vector<kg_progress> prog;
+            std::vector<uint32_t> slots;                           // (several batches only: a k-mer found in two counts once)
             int64_t a = 0;
             while (a < n) {
                 int64_t b = a;
@@ -484,27 +460,60 @@ int main(int argc, char **argv)
                 for (int64_t k = a; k <= b; k++) boff[(size_t)(k - a)] = fa.off[(size_t)k] - fa.off[(size_t)a];
                 kg_result *res = nullptr;
                 check(kg_scan(tab, &pc, fa.seq.data() + fa.off[(size_t)a], boff.data(), b - a, &res));
-                const kg_hit *hits = kg_result_hits(res);
-                const int64_t *chs = kg_result_container_hit_start(res);
-                if (!hits || !chs) die(std::string("libkmerguts_hip: ") + kg_last_error());
                 kg_stats stc;
                 check(kg_result_stats(res, &stc));
-                ran_off = ran_off || stc.lookup_ran_off;
-                for (int64_t k = a; k < b; k++)
-                    for (int f = 0; f < per; f++) {
-                        const int64_t cont = (k - a) * per + f;
-                        for (int64_t i = chs[cont]; i < chs[cont + 1]; i++)
-                            distinct.insert(kmer_value_at(fa.seq.data() + fa.off[(size_t)k], fa.off[(size_t)k + 1] - fa.off[(size_t)k],
-                                                          o.aa, f, hits[i].from0InProt));
-                        pos_count += chs[cont + 1] - chs[cont];
-                    }
+                kg_progress g;
+                check(kg_result_progress(res, &g));
+                prog.push_back(g);
+                pos_count += stc.n_hits;
+                if (!(a == 0 && b == n) && stc.n_hits) {
+                    const uint32_t *hs = kg_result_hit_slots(res);
+                    if (!hs) die(std::string("libkmerguts_hip: ") + kg_last_error());
+                    slots.insert(slots.end(), hs, hs + stc.n_hits);
+                }
                 kg_result_free(res);
                 a = b;
             }
-            // a query that walks off the end of the table makes the reference's stream throw EOFException: run() prints
-            // "Error: null" and carries on, "Kmers found" is not reached (KGJ:797-802)
-            if (ran_off) { info("Error: null"); error_reported = true; }
-            else out.put("Kmers found: " + std::to_string(distinct.size()) + " (pos-count=" + std::to_string(pos_count) + ")\n");
+            if (!prog.empty()) {
+                int64_t first[11], found_upto[11], last = -1, beyond = -1, kmers_found = 0;
+                bool walk_ran_off = false;
+                for (int f = 0; f <= 10; f++) { first[f] = -1; found_upto[f] = 0; }
+                for (const kg_progress &g : prog) {                // the join runs in slot order: minimum / maximum over the batches
+                    for (int f = 0; f <= 10; f++)
+                        if (g.first_visited[f] >= 0 && (first[f] < 0 || g.first_visited[f] < first[f])) first[f] = g.first_visited[f];
+                    last = std::max(last, g.last_visited);
+                    if (g.first_beyond >= 0 && (beyond < 0 || g.first_beyond < beyond)) beyond = g.first_beyond;
+                    walk_ran_off = walk_ran_off || g.walk_ran_off;
+                }
+                if (prog.size() == 1) {
+                    for (int f = 0; f <= 10; f++) found_upto[f] = prog[0].found_upto[f];
+                    kmers_found = prog[0].kmers_found;
+                } else {
+                    std::sort(slots.begin(), slots.end());
+                    slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+                    kmers_found = (int64_t)slots.size();
+                    for (int f = 0; f <= 10; f++)
+                        if (first[f] >= 0) found_upto[f] = std::upper_bound(slots.begin(), slots.end(), (uint32_t)first[f]) - slots.begin();
+                }
+                for (int f = 1; f <= 10; f++)                      // (tenth 0 is where the join starts: never a change)
+                    if (first[f] >= 0)
+                        info("Processed: " + std::to_string(f * 10) + "%, time=" + std::to_string(now_ms() - t2) + " ms., found-so-far=" +
+                             std::to_string(found_upto[f]));
+                const bool gz = table.size() > 3 && table.compare(table.size() - 3, 3, ".gz") == 0;
+                if (walk_ran_off) {
+                    // a query that walks off the end of the table makes the reference's stream throw EOFException: run() prints
+                    // "Error: null" and carries on, "Kmers found" is not reached (KGJ:797-802)
+                    info("Error: null");
+                } else if (beyond >= 0) {
+                    // a table stream shorter than numSigs records and a query whose home slot lies behind its end: the join skips to
+                    // it -- a GZIPInputStream comes up short ("Error skipping N bytes", KGJ:1036-1049), a plain file seeks past its
+                    // end and the read behind it throws EOFException
+                    const long long skip = 24ll * (beyond - (last + 1));
+                    info(gz && skip > 0 ? "Error: Error skipping " + std::to_string(skip) + " bytes" : std::string("Error: null"));
+                } else if (o.debug) {
+                    out.put("Kmers found: " + std::to_string(kmers_found) + " (pos-count=" + std::to_string(pos_count) + ")\n");
+                }
+            }
         }
         long long t_group = 0;
         size_t at = 0;
@@ -543,12 +552,6 @@ int main(int argc, char **argv)
                 hits = kg_result_hits(res); chs = kg_result_container_hit_start(res);
                 ev = kg_result_hit_events(res); tail = kg_result_container_tail_events(res);
                 if (!hits || !chs || !ev || !tail) die(std::string("libkmerguts_hip: ") + kg_last_error());
-            }
-            // with one batch (inputs up to ~1.5 Gbp) the info lines sit exactly where the reference prints them
-            if (!error_reported) {
-                kg_stats stb;
-                check(kg_result_stats(res, &stb));
-                if (stb.lookup_ran_off) { info("Error: null"); error_reported = true; }    // KGJ:797-802
             }
             if (at == 0) info("Lookup time: " + std::to_string(now_ms() - t2) + " ms.");
             long long t3 = now_ms();

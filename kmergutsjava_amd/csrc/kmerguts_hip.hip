@@ -216,9 +216,12 @@ struct kg_result {
     int64_t *d_ccs = nullptr;
     kg_otu *d_otu = nullptr;
     uint8_t *d_ev = nullptr, *d_tail_ev = nullptr;   // KG_EV_* per hit / per container
+    uint32_t *d_hit_slots = nullptr;                 // KG_F_PROGRESS: the slot every hit was found at
+    bool has_progress = false;
+    kg_progress progress = {};
     // host copies (lazy), in pinned memory so the copy runs at PCIe rate
     void *h_hits = nullptr, *h_chs = nullptr, *h_ccs = nullptr, *h_calls = nullptr, *h_otu = nullptr, *h_ev = nullptr,
-         *h_tail_ev = nullptr;
+         *h_tail_ev = nullptr, *h_hit_slots = nullptr;
 };
 
 namespace {
@@ -581,9 +584,9 @@ void kg_result_free(kg_result *r)
     if (t) {
         // a result is only handed out after its scan has synchronised the stream
         dfree(t, r->d_hits); dfree(t, r->d_chs); dfree(t, r->d_calls); dfree(t, r->d_ccs); dfree(t, r->d_otu);
-        dfree(t, r->d_ev); dfree(t, r->d_tail_ev);
+        dfree(t, r->d_ev); dfree(t, r->d_tail_ev); dfree(t, r->d_hit_slots);
     }
-    for (void *h : {r->h_hits, r->h_chs, r->h_ccs, r->h_calls, r->h_otu, r->h_ev, r->h_tail_ev})
+    for (void *h : {r->h_hits, r->h_chs, r->h_ccs, r->h_calls, r->h_otu, r->h_ev, r->h_tail_ev, r->h_hit_slots})
         if (h) { if (t) t->pins.put(h); else (void)hipHostFree(h); }
     if (t && r->own_tab) kg_table_close(t);
     delete r;
@@ -765,7 +768,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         return KG_OK;
     };
     constexpr uint32_t PER = AA ? 1 : 6;
-    const bool counters = (p->flags & KG_F_COUNTERS) != 0;
+    const bool progress = (p->flags & KG_F_PROGRESS) != 0;
+    const bool counters = (p->flags & KG_F_COUNTERS) != 0 || progress;       // the walks are noted by the counting kernels
     kg_stats &st = res->st;
     res->per = PER;
 
@@ -825,6 +829,29 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
 
     if ((rc = dalloc(t, (void **)&res->d_chs, (n_cont + 1) * 8))) return rc;
 
+    // KG_F_PROGRESS: the walks' summary (kg_device.hpp, Progress).  lo[f] = the smallest slot of tenth >= f, found with the
+    // reference's own double arithmetic (KGJ:1018) around ceil(f * numSigs / 10) - 1
+    kg::Progress *d_prog = nullptr;
+    if (progress) {
+        if (t->limit > 0xFFFFFFFFull) return fail(KG_ERR_UNSUPPORTED, "KG_F_PROGRESS: table streams of 2^32 records or more");
+        if ((rc = sc.get(&d_prog, 1))) return rc;
+        kg::Progress h;
+        for (auto &x : h.first) x = ~0ull;
+        h.last_plus1 = 0; h.first_beyond = ~0ull; h.walk_ran_off = 0;
+        for (auto &x : h.found_upto) x = 0;
+        h.kmers_found = 0;
+        const double n = (double)t->num_sigs;
+        auto tenth = [&](uint64_t s) { return (int)(10.0 * ((double)(s + 1) / n)); };
+        for (int f = 0; f <= 10; f++) {
+            const unsigned __int128 num = (unsigned __int128)(uint64_t)t->num_sigs * (unsigned)f;
+            uint64_t s = (uint64_t)((num + 9) / 10);
+            s = s > 3 ? s - 3 : 0;
+            while (tenth(s) < f) s++;
+            h.lo[f] = s;
+        }
+        HIP_TRY(hipMemcpyAsync(d_prog, &h, sizeof h, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));                             // (h is a stack object)
+    }
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     if (nblocks) {
         hipLaunchKernelGGL(kg::build_blocks_kernel, dim3((uint32_t)((nblocks + 255) / 256)), dim3(256), 0, t->stream,
@@ -1017,6 +1044,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             const uint64_t hits_cap = ucap * n_chunks_p;
             const size_t cused_stride = (size_t)(ucap / kg::kUChunk + 1), candused_stride = (size_t)(ccap / kg::kUChunk + 1);
             if ((rc = dalloc(t, (void **)&res->d_hits, hits_cap * sizeof(kg_hit)))) return rc;
+            if (progress && (rc = dalloc(t, (void **)&res->d_hit_slots, hits_cap * 4))) return rc;
             if ((rc = dalloc(t, (void **)&d_ulist, ucap * n_chunks_p * sizeof(kg_hit)))) return rc;
             if ((rc = dalloc(t, (void **)&d_cused, cused_stride * n_chunks_p * 4))) return rc;
             if ((rc = dalloc(t, (void **)&d_cand, ccap * n_chunks_p * sizeof(kg::CandRec)))) return rc;
@@ -1065,7 +1093,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 if (!seq_uploaded && (rc = upload(offsets[cseq[c]], offsets[cseq[c + 1]]))) return rc;
                 hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
                                    d_blocks, lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
-                                   cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, ovfc_c + 1, d_lowc + lo, d_ctr);
+                                   cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, ovfc_c + 1, d_lowc + lo, d_ctr, d_prog);
                 hipStream_t s2 = t->stream2, s3 = t->stream3;
                 HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
                 HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
@@ -1076,10 +1104,10 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 // the CUs (profiles/r02_pipeline.md).
                 hipLaunchKernelGGL((kg::lowc_blocks_kernel<AA>), dim3(lowc_grid), dim3(64 * kg::kLowcWaves), 0, s2, d_seq, d_blocks, ovfc_c + 1, d_lowc + lo,
                                    t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, n_wg, cap, ent_c, fill_c, ovfc_c, ovf_cap,
-                                   ovf_bucket_c, ovf_ent_c, d_ctr);
+                                   ovf_bucket_c, ovf_ent_c, d_ctr, d_prog);
 #define KG_TAG_ARGS t->d_tags, t->limit, (uint64_t)t->num_sigs, ent_c, fill_c, n_wg, cap, part_buckets, part_shift, probe_grab, next_c, cand_c, \
                     candused_c, ccur_c, ccap, d_ctr
-#define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_ctr
+#define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_ctr, d_prog
                 if (use_bidx) {
 #define KG_INDEX_ARGS t->d_bidx, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent_c, fill_c, n_wg, cap, \
                       part_buckets, part_shift, probe_grab, next_c, cand_c, candused_c, ccur_c, ccap, d_ctr
@@ -1091,8 +1119,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
 #undef KG_INDEX_LAUNCH
 #undef KG_INDEX_ARGS
                 }
-                else if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
-                else hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS);
+                else if (counters) hipLaunchKernelGGL((kg::bucket_tag_kernel<true>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS, d_prog);
+                else hipLaunchKernelGGL((kg::bucket_tag_kernel<false>), dim3(probe_grid), dim3(256), 0, s2, KG_TAG_ARGS, (kg::Progress *)nullptr);
                 HIP_TRY(hipEventRecord(t->pev[2 * c + 1], s2));
                 HIP_TRY(hipStreamWaitEvent(s3, t->pev[2 * c + 1], 0));
                 if (counters) {
@@ -1168,7 +1196,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                     hipLaunchKernelGGL((kg::group_place_kernel<AA>), dim3(std::min(n_groups, 256u * 8u)), dim3(kg::kHThreads),
                                        kg::group_place_lds(gshift, place_staged), s3,
                                        sortB_c, gbase_c, n_groups, g0, gshift, (uint32_t)row_lo, (uint32_t)row_hi, d_geo, (uint64_t)n_rows,
-                                       place_staged ? 1u : 0u, base_c, res->d_hits, hits_cap, d_offs);
+                                       place_staged ? 1u : 0u, base_c, res->d_hits, hits_cap, d_offs, res->d_hit_slots);
                 }
                 HIP_TRY(hipGetLastError());
             }
@@ -1213,6 +1241,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             // a list was too small: now the exact need is known (masks are cleared and everything is redone)
             dfree(t, d_ulist); dfree(t, d_cused); dfree(t, d_cand); dfree(t, d_candused); dfree(t, res->d_hits);   // both streams are idle
             dfree(t, d_sortA); dfree(t, d_sortB);                         // (the ordering buffers are sized by ucap as well)
+            dfree(t, res->d_hit_slots); res->d_hit_slots = nullptr;
             d_ulist = nullptr; d_cused = nullptr; d_cand = nullptr; d_candused = nullptr; res->d_hits = nullptr;
             d_sortA = nullptr; d_sortB = nullptr;
             if (attempt == 2) return fail(KG_ERR_DEVICE, "hit list overflow after resize (internal error)");
@@ -1221,8 +1250,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             else ucap = (need_u + list_slack + kg::kUChunk - 1) / kg::kUChunk * kg::kUChunk;
         }
         if (too_skewed) {
-            dfree(t, res->d_hits);
-            res->d_hits = nullptr;
+            dfree(t, res->d_hits); dfree(t, res->d_hit_slots);
+            res->d_hits = nullptr; res->d_hit_slots = nullptr;
         } else {
             st.windows_valid = counters ? (int64_t)h_tot[2] : -1;
             st.slots_inspected = counters ? (int64_t)h_tot[3] : -1;
@@ -1253,9 +1282,11 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
     if (stage_cap > 0xFFFFFF00ull) stage_cap = 0xFFFFFF00ull;
     if (test_hook("KG_TEST_TINY_LISTS")) stage_cap = 256;                    // tests: force the resize-and-rerun path
     kg_hit *d_stage = nullptr;
-    struct StageGuard { Scratch &sc; kg_hit *&p; ~StageGuard() { if (p) sc.adopt(p); } } stage_guard{sc, d_stage};
+    uint32_t *d_stage_slot = nullptr;                                        // KG_F_PROGRESS: the found slots, parallel to d_stage
+    struct StageGuard { Scratch &sc; kg_hit *&p; uint32_t *&q; ~StageGuard() { if (p) sc.adopt(p); if (q) sc.adopt(q); } } stage_guard{sc, d_stage, d_stage_slot};
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = dalloc(t, (void **)&d_stage, stage_cap * sizeof(kg_hit)))) return rc;
+        if (progress && (rc = dalloc(t, (void **)&d_stage_slot, stage_cap * 4))) return rc;
         unsigned long long *d_cursor = (unsigned long long *)(d_totals + 1);
         unsigned long long *d_ctr = (unsigned long long *)(d_totals + 2);
         HIP_TRY(hipMemsetAsync(d_totals, 0, 64, t->stream));
@@ -1264,7 +1295,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             uint64_t wgs = (nblocks + kg::kWavesPerWG - 1) / kg::kWavesPerWG;
             uint32_t grid = (uint32_t)(wgs < scan_grid ? wgs : scan_grid);      // persistent waves stride over the blocks
 #define KG_SCAN_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic, t->m35, d_seq, d_blocks, (uint32_t)nblocks, \
-                     d_counts, d_bsb, d_stage, d_cursor, stage_cap, stage_chunk, d_ctr
+                     d_counts, d_bsb, d_stage, d_cursor, stage_cap, stage_chunk, d_ctr, d_prog, d_stage_slot
 #define KG_SCAN_LAUNCH(C, R) hipLaunchKernelGGL((kg::scan_kernel<AA, C, R>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, \
                                                 t->stream, KG_SCAN_ARGS)
             if (AA) {
@@ -1296,6 +1327,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         if (h_tot[1] <= stage_cap) break;
         // staging overflow: now the exact need is known
         dfree(t, d_stage); d_stage = nullptr;
+        dfree(t, d_stage_slot); d_stage_slot = nullptr;
         if (attempt == 1) return fail(KG_ERR_DEVICE, "staging overflow after resize (internal error)");
         stage_cap = h_tot[1];
     }
@@ -1307,11 +1339,24 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
 
     // ---- ordered placement ----
     if ((rc = dalloc(t, (void **)&res->d_hits, n_hits * sizeof(kg_hit)))) return rc;
+    if (progress && (rc = dalloc(t, (void **)&res->d_hit_slots, (n_hits ? n_hits : 1) * 4))) return rc;
     if (nblocks) {
         uint32_t grid = (uint32_t)((nblocks + kg::kWavesPerWG - 1) / kg::kWavesPerWG);
         hipLaunchKernelGGL((kg::place_kernel<AA>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, t->stream, d_blocks,
-                           (uint32_t)nblocks, d_counts, d_offs, d_bsb, rpg, d_stage, res->d_hits);
+                           (uint32_t)nblocks, d_counts, d_offs, d_bsb, rpg, d_stage, res->d_hits, d_stage_slot, res->d_hit_slots);
     }
+    }
+    if (progress) {
+        // kmersFound / found-so-far: the distinct slots of the hit records (a bitmap over the stream's slots)
+        uint32_t *d_bitmap = nullptr;
+        const uint64_t n_words = (t->limit + 31) / 32 + 1;
+        if ((rc = sc.get(&d_bitmap, (size_t)n_words))) return rc;
+        HIP_TRY(hipMemsetAsync(d_bitmap, 0, n_words * 4, t->stream));
+        if (n_hits)
+            hipLaunchKernelGGL(kg::mark_found_kernel, dim3((uint32_t)std::min<uint64_t>(2048, (n_hits + 255) / 256)), dim3(256), 0, t->stream,
+                               res->d_hit_slots, n_hits, d_bitmap);
+        hipLaunchKernelGGL(kg::count_found_kernel, dim3((uint32_t)std::min<uint64_t>(2048, (n_words + 255) / 256)), dim3(256), 0, t->stream,
+                           d_bitmap, n_words, d_prog);
     }
     hipLaunchKernelGGL((kg::container_starts_kernel<AA>), dim3((uint32_t)((n_cont + 1 + 255) / 256)), dim3(256), 0, t->stream,
                        d_ibase, (uint32_t)n_seqs, d_offs, n_rows, d_totals, res->d_chs);
@@ -1325,6 +1370,19 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
     HIP_TRY(hipEventRecord(t->ev[4], t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     st.n_calls = aggregate ? (int64_t)t->h_pin[kPinCalls] : 0;
+    if (progress) {
+        kg::Progress h;
+        HIP_TRY(hipMemcpy(&h, d_prog, sizeof h, hipMemcpyDeviceToHost));
+        kg_progress &g = res->progress;
+        for (int f = 0; f <= 10; f++) g.first_visited[f] = h.first[f] == ~0ull ? -1 : (int64_t)h.first[f];
+        g.last_visited = (int64_t)h.last_plus1 - 1;
+        g.first_beyond = h.first_beyond == ~0ull ? -1 : (int64_t)h.first_beyond;
+        g.walk_ran_off = h.walk_ran_off ? 1 : 0;
+        g.stream_slots = (int64_t)t->limit;
+        for (int f = 0; f <= 10; f++) g.found_upto[f] = g.first_visited[f] < 0 ? 0 : (int64_t)h.found_upto[f];
+        g.kmers_found = (int64_t)h.kmers_found;
+        res->has_progress = true;
+    }
     st.agg_pieces = aggregate ? (int32_t)std::min<uint64_t>(t->h_pin[kPinPieces], 0x7FFFFFFF) : 0;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, t->ev[1], t->ev[2])); st.ms_scan = ms;
@@ -1550,6 +1608,20 @@ const uint8_t *kg_result_container_tail_events(kg_result *r)
     if (!r->d_tail_ev) { g_err = "events not computed (KG_F_SKIP_AGGREGATE)"; return nullptr; }
     return host_view(r, r->h_tail_ev, r->d_tail_ev, (size_t)r->st.n_containers);
 }
+const uint32_t *kg_result_hit_slots(kg_result *r)
+{
+    if (!r || !r->has_progress) { g_err = "hit slots are recorded by KG_F_PROGRESS scans only"; return nullptr; }
+    return host_view<uint32_t>(r, r->h_hit_slots, r->d_hit_slots, (size_t)r->st.n_hits);
+}
+
+int kg_result_progress(const kg_result *r, kg_progress *out)
+{
+    if (!r || !out) return fail(KG_ERR_ARG, "null argument");
+    if (!r->has_progress) return fail(KG_ERR_ARG, "not a KG_F_PROGRESS scan");
+    *out = r->progress;
+    return KG_OK;
+}
+
 int kg_result_copy_hits(kg_result *r, int64_t first, int64_t count, kg_hit *dst)
 {
     if (!r || first < 0 || count < 0 || first + count > r->st.n_hits) return fail(KG_ERR_ARG, "hit range out of bounds");

@@ -27,9 +27,11 @@ class Params:
     max_gap: int = 200
     counters: bool = False
     skip_aggregate: bool = False
+    progress: bool = False          # KG_F_PROGRESS: ScanResult.progress() / .hit_slots() (the "Processed: NN%" lines, KGJ:1016-1025)
 
     def to_native(self) -> N.KgParams:
-        flags = (N.KG_F_COUNTERS if self.counters else 0) | (N.KG_F_SKIP_AGGREGATE if self.skip_aggregate else 0)
+        flags = ((N.KG_F_COUNTERS if self.counters else 0) | (N.KG_F_SKIP_AGGREGATE if self.skip_aggregate else 0) |
+                 (N.KG_F_PROGRESS if self.progress else 0))
         return N.KgParams(int(self.aa), int(self.order_constraint), int(self.min_hits),
                           int(self.min_weighted_hits), int(self.max_gap), flags)
 
@@ -109,6 +111,22 @@ class ScanResult:
     def container_tail_events(self) -> np.ndarray:
         lib = self._need()
         return N.view(lib.kg_result_container_tail_events(self._h), self.stats["n_containers"], np.dtype("u1"))
+
+    def hit_slots(self) -> np.ndarray:
+        """KG_F_PROGRESS scans: the table slot every hit record was found at (uint32, parallel to hits())."""
+        lib = self._need()
+        ptr = lib.kg_result_hit_slots(self._h)
+        if not ptr and self.stats["n_hits"]:
+            raise N.KmerGutsNativeError(-1, (lib.kg_last_error() or b"").decode())
+        return N.view(ptr, self.stats["n_hits"], np.dtype("<u4"))
+
+    def progress(self) -> dict:
+        """KG_F_PROGRESS scans: kg_progress as a dict (first slot visited per tenth of the table, last slot visited, first
+        home slot behind the end of a short table stream, whether a walk ran off its end, records in the stream)."""
+        lib = self._need()
+        p = N.KgProgress()
+        N.check(lib.kg_result_progress(self._h, C.byref(p)))
+        return p.as_dict()
 
     def device_hits_ptr(self) -> int:
         return self._need().kg_result_device_hits(self._h) or 0

@@ -430,17 +430,23 @@ class KmerGutsJava:
         t2 = time.time()
         if self.debug:                                            # KGJ:951-954
             pw.write("Kmer-table info: numSigs=%(numSigs)d, entrySize=%(entrySize)d, version=%(version)d\n" % tab.info())
+        # the info lines of the lookup ("Processed: NN%", "Kmers found", "Error: ...") are printed when -d is given or the
+        # report goes to a file (printInfoLine, KGJ:891-898); they need what the reference's table stream would have seen
+        # (KG_F_PROGRESS), over every FASTA record.  Otherwise the plain, faster scan.
+        need_info = self.debug or not stdout
         params = Params(aa=self.aa, order_constraint=self.orderConstraint, min_hits=self.minHits,
-                        min_weighted_hits=self.minWeightedHits, max_gap=self.maxGap)
+                        min_weighted_hits=self.minWeightedHits, max_gap=self.maxGap, progress=need_info)
         per = 1 if self.aa else 6
         results = {}                    # record index -> (calls of its containers, otu record)
         self.last_stats = []
         batch: List[int] = []
         size = 0
-        found_values: List[np.ndarray] = []     # -d: the k-mer value of every hit record (KGJ:1004-1015)
+        progress: List[dict] = []               # per batch: kg_progress
+        found_slots: List[np.ndarray] = []      # per batch: the distinct table slots of its hit records
+        pos_count = 0                           # hit records (KGJ:1014)
 
         def flush():
-            nonlocal batch, size
+            nonlocal batch, size, pos_count
             if not batch:
                 return
             off = np.zeros(len(batch) + 1, dtype=np.int64)
@@ -451,29 +457,28 @@ class KmerGutsJava:
                 if self.debug:      # -d: the hit records and what gatherHits did at each of them
                     hits, chs, ev, tail = r.hits(), r.container_hit_start(), r.hit_events(), r.container_tail_events()
                 self.last_stats.append(r.stats)
+                if need_info:
+                    progress.append(r.progress())
+                    pos_count += r.stats["n_hits"]
+                    found_slots.append(np.unique(r.hit_slots()) if size_total > self.MAX_BATCH_CHARS else None)
             for j, k in enumerate(batch):
                 cs = range(j * per, j * per + per)
                 dbg = [(hits[chs[c]:chs[c + 1]], ev[chs[c]:chs[c + 1]], int(tail[c])) for c in cs] if self.debug else None
                 results[k] = ([calls[ccs[c]:ccs[c + 1]] for c in cs], otu[j], dbg)
-                if self.debug:
-                    found_values.append(hit_kmer_values(seqs[k], self.aa, [d[0]["from0InProt"] for d in dbg]))
             batch, size = [], 0
 
         # -d counts what the reference's lookup counts: every FASTA record has containers of its own there, also a
         # record that a later one of the same id shadows in the report (KGJ:805-809)
-        for k in (range(len(ids)) if self.debug else order):
+        scan_order = range(len(ids)) if need_info else order
+        size_total = sum(len(seqs[k]) for k in scan_order)        # (more than one batch: the distinct slots are combined here)
+        for k in scan_order:
             if batch and size + len(seqs[k]) > self.MAX_BATCH_CHARS:
                 flush()
             batch.append(k)
             size += len(seqs[k])
         flush()
-        if any(st["lookup_ran_off"] for st in self.last_stats):
-            # a query walked to the end of the table undecided: there the reference's stream throws EOFException,
-            # which run() reports and swallows (KGJ:797-802); the hits are the same, "Kmers found" is not reached
-            self._info("Error: null", pw, stdout)
-        elif self.debug:                                          # KGJ:1031-1033
-            vals = np.concatenate(found_values) if found_values else np.zeros(0, np.int64)
-            pw.write("Kmers found: %d (pos-count=%d)\n" % (len(np.unique(vals)), len(vals)))
+        if need_info:
+            self._lookup_info(progress, found_slots, pos_count, table_path.endswith(".gz"), t2, pw, stdout)
         self._info("Lookup time: %d ms." % int((time.time() - t2) * 1000), pw, stdout)
 
         t3 = time.time()
@@ -482,6 +487,39 @@ class KmerGutsJava:
             self.write_record(pw, ids[k], len(seqs[k]), calls, otu, function_array, dbg)
         pw.flush()
         self._info("Grouping time: %d ms." % int((time.time() - t3) * 1000), pw, stdout)
+
+    def _lookup_info(self, progress: List[dict], found_slots, pos_count: int, gz: bool, t2: float, pw, stdout: bool) -> None:
+        """What lookup prints besides the records (KGJ:1016-1033) and how run() reports its failure (KGJ:797-802), from the
+        scans' kg_progress: the merge-join visits the table in slot order, so the batches' summaries combine by minimum and
+        maximum; one "Processed" line per tenth of the table in which a slot was visited, at the first such slot."""
+        if not progress:
+            return
+        first = [min([p["first_visited"][f] for p in progress if p["first_visited"][f] >= 0], default=-1) for f in range(11)]
+        last = max(p["last_visited"] for p in progress)
+        beyond = min([p["first_beyond"] for p in progress if p["first_beyond"] >= 0], default=-1)
+        ran_off = any(p["walk_ran_off"] for p in progress)
+        if len(progress) == 1:
+            found_upto, kmers_found = progress[0]["found_upto"], progress[0]["kmers_found"]
+        else:                                                     # a k-mer found in two batches counts once
+            slots = np.unique(np.concatenate([x for x in found_slots if x is not None])) if any(x is not None for x in found_slots) else np.zeros(0, np.uint32)
+            found_upto = [int(np.searchsorted(slots, first[f], side="right")) if first[f] >= 0 else 0 for f in range(11)]
+            kmers_found = len(slots)
+        for f in range(1, 11):                                    # (tenth 0 is where the join starts: never a change)
+            if first[f] >= 0:
+                self._info("Processed: %d%%, time=%d ms., found-so-far=%d" % (f * 10, int((time.time() - t2) * 1000), found_upto[f]),
+                           pw, stdout)
+        if ran_off:
+            # a query walked to the end of the table undecided: there the reference's stream throws EOFException,
+            # which run() reports and swallows (KGJ:797-802); the hits are the same, "Kmers found" is not reached
+            self._info("Error: null", pw, stdout)
+        elif beyond >= 0:
+            # the table stream is shorter than numSigs records and a query's home slot lies behind its end: the join skips
+            # to it -- a GZIPInputStream comes up short ("Error skipping N bytes", KGJ:1036-1049), a plain file seeks past
+            # its end and the read behind it throws EOFException
+            skip = 24 * (beyond - (last + 1))
+            self._info("Error: Error skipping %d bytes" % skip if gz and skip > 0 else "Error: null", pw, stdout)
+        elif self.debug:                                          # KGJ:1031-1033
+            pw.write("Kmers found: %d (pos-count=%d)\n" % (kmers_found, pos_count))
 
     def write_record(self, pw, name: str, ln: int, calls_per_container, otu, function_array, debug_per_container=None) -> None:
         """The report of one sequence: processSeq / processAASeq + tabulateOtuDataForContig

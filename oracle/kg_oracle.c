@@ -281,13 +281,15 @@ static inline float rd_f32le(const uint8_t *b)
  * (EOFException / failed skip -> swallowed at KGJ:799-802), 0 otherwise, -1 on OOM. */
 typedef struct { int64_t value; int64_t first, count; } group;   /* one inProgress map entry */
 static int lookup_literal(const uint8_t *file, int64_t file_n, int64_t numSigs, int64_t entrySize,
-                          const query_kmer *qs, int64_t nq, hvec *hits)
+                          const query_kmer *qs, int64_t nq, hvec *hits, kgo_result *out)
 {
     int64_t cursor = 0;                 /* stream position */
     int64_t curHashCode = 0;
     int64_t cur = 0;                    /* kmerStorage.loadNext() index */
     group *inProgress = NULL; int64_t ng = 0, gcap = 0;
     int aborted = 0;
+    int64_t kmersFound = 0;             /* KGJ:956 */
+    int fraction = 0;                   /* KGJ:963 */
     while (cur < nq || ng > 0) {
         int64_t neededHashCode = curHashCode;
         if (ng == 0) {                                          /* KGJ:966-974 */
@@ -317,11 +319,17 @@ static int lookup_literal(const uint8_t *file, int64_t file_n, int64_t numSigs, 
         }
         if (neededHashCode > curHashCode) {                     /* KGJ:991-994 skipBytesFully */
             int64_t skip = entrySize * (neededHashCode - curHashCode);
-            if (skip > file_n - cursor) { aborted = 1; break; } /* KGJ:1045-1047 -> swallowed */
+            if (skip > file_n - cursor) {                       /* KGJ:1045-1047 -> swallowed */
+                if (out->skip_failed_bytes < 0 && !out->read_eof) out->skip_failed_bytes = skip;
+                aborted = 1; break;
+            }
             if (skip > 0) cursor += skip;
             curHashCode = neededHashCode;
         }
-        if (file_n - cursor < 24) { aborted = 1; break; }       /* EOFException KGJ:1102,1116 */
+        if (file_n - cursor < 24) {                             /* EOFException KGJ:1102,1116 */
+            if (out->skip_failed_bytes < 0) out->read_eof = 1;
+            aborted = 1; break;
+        }
         const uint8_t *e = file + cursor;                       /* KGJ:995-999 */
         int64_t whichKmer = rd_i64le(e);
         int32_t otuIndex = rd_i32le(e + 8);
@@ -335,6 +343,7 @@ static int lookup_literal(const uint8_t *file, int64_t file_n, int64_t numSigs, 
             int64_t g;
             for (g = 0; g < ng; g++) if (inProgress[g].value == whichKmer) break;
             if (g < ng) {                                       /* KGJ:1004-1015 */
+                kmersFound++;
                 for (int64_t k = 0; k < inProgress[g].count; k++) {
                     const query_kmer *qk = &qs[inProgress[g].first + k];
                     kgo_hit_rec h;
@@ -348,7 +357,19 @@ static int lookup_literal(const uint8_t *file, int64_t file_n, int64_t numSigs, 
             }
         }
         curHashCode++;
+        {                                                       /* KGJ:1017-1024 */
+            int newFraction = (int)(10.0 * ((double)curHashCode / (double)numSigs));
+            if (newFraction != fraction) {
+                fraction = newFraction;
+                if (out->n_processed < KGO_MAX_PROCESSED) {
+                    out->processed_tenth[out->n_processed] = fraction;
+                    out->processed_found[out->n_processed] = kmersFound;
+                    out->n_processed++;
+                }
+            }
+        }
     }
+    out->kmers_found += kmersFound;
     free(inProgress);
     return aborted;
 }
@@ -577,6 +598,7 @@ int kgo_run(const uint8_t *table, size_t table_nbytes, const kgo_params *p,
             kgo_result *out)
 {
     memset(out, 0, sizeof *out);
+    out->skip_failed_bytes = -1;
     if (table_nbytes < 24) return fail("table image shorter than its 24-byte header");
     /* KGJ:933-935 */
     int64_t numSigs = rd_i64le(table);
@@ -622,7 +644,7 @@ int kgo_run(const uint8_t *table, size_t table_nbytes, const kgo_params *p,
         double t1 = now_s();
         out->t_prepare += t1 - t0;
         if (lookup_mode == 0) {
-            int a = lookup_literal(file, file_n, numSigs, entrySize, q.a, q.n, &hits);
+            int a = lookup_literal(file, file_n, numSigs, entrySize, q.a, q.n, &hits, out);
             if (a < 0) { rc = fail("out of memory in lookup"); break; }
             if (a) out->lookup_aborted = 1;
         } else {

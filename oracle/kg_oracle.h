@@ -49,6 +49,7 @@ typedef struct { uint32_t container; int32_t from0InProt, oI, avgOffFromEnd, fI;
 typedef struct { uint32_t container; int32_t start, end, count, fI; float weightedHits; } kgo_call_rec;
 typedef struct { int32_t n; int32_t count[KGO_OI_BUFSZ]; int32_t oI[KGO_OI_BUFSZ]; } kgo_otu_rec;
 
+#define KGO_MAX_PROCESSED 64
 typedef struct {
     int64_t n_seqs;
     int64_t n_containers;
@@ -68,6 +69,18 @@ typedef struct {
                                        threw; direct mode = a probe walk reached the end of the records undecided */
     uint8_t *hit_events;            /* n_hits: KGO_EV_* of each record (the -d stream, see gather_sorted) */
     uint8_t *container_tail_events; /* n_containers: KGO_EV_TAIL_CALL                               */
+    /* literal mode only: what the reference's table stream reports while the merge-join runs (KGJ:1016-1025: one
+     * "Processed: <10 tenth>%, time=..., found-so-far=<kmersFound>" line whenever the tenth of the table changes), in print
+     * order over all batches (at most KGO_MAX_PROCESSED lines kept), the distinct k-mers found (KGJ:1004-1006) and how the
+     * stream failed, if it did */
+    int32_t n_processed;
+    int32_t processed_tenth[KGO_MAX_PROCESSED];
+    int64_t processed_found[KGO_MAX_PROCESSED];
+    int64_t kmers_found;            /* kmersFound summed over the batches                                        */
+    int64_t skip_failed_bytes;      /* -1, or N of "Error skipping N bytes" (KGJ:1036-1049): the skip to the next home slot
+                                       asked for more than the stream holds.  A .gz stream fails there; a plain file's skip
+                                       succeeds and the read behind it throws EOFException instead                        */
+    int32_t read_eof;               /* the merge-join read past the end of the stream (EOFException, KGJ:1097-1126)        */
 } kgo_result;
 
 /* what the reference's -d stream shows at one hit record, in the order it happens */

@@ -139,11 +139,17 @@ def java_format_f(v: float, precision: int = 6) -> str:
     return s
 
 
+class SkipError(Exception):
+    """IllegalStateException("Error skipping N bytes") of skipBytesFully, KGJ:1045-1047."""
+
+
 class Model:
-    """Instance fields of KGJ:102-109 + the methods that read them."""
+    """Instance fields of KGJ:102-109 + the methods that read them.  gz: the table is read through a GZIPInputStream
+    (kmer.table.mem_map.gz, KGJ:927-929), which matters only for how a stream shorter than numSigs records fails."""
 
     def __init__(self, aa=False, order_constraint=False, min_hits=5, min_weighted_hits=0,
-                 max_gap=200, debug=False):
+                 max_gap=200, debug=False, gz=False):
+        self.gz = gz
         self.aa = aa
         self.orderConstraint = order_constraint
         self.minHits = min_hits
@@ -306,6 +312,8 @@ class Model:
     def lookup(self, stream: io.BytesIO, num_sigs, entry_size, query_kmers, hit_cnts):
         self.kmers_found = 0                                            # KGJ:956-957
         self.pos_count = 0
+        self.processed = []                                             # (tenth, found-so-far) of every "Processed:" line
+        fraction = 0                                                    # KGJ:963
         cur_hash = 0
         it = iter(query_kmers)
         cur = next(it, None)
@@ -324,11 +332,14 @@ class Model:
                 in_progress.setdefault(qk[0], []).append(qk)
                 cur = next(it, None)
             if needed > cur_hash:
-                to_skip = entry_size * (needed - cur_hash)
+                to_skip = entry_size * (needed - cur_hash)                  # KGJ:991-994 skipBytesFully
                 before = stream.tell()
                 stream.seek(to_skip, io.SEEK_CUR)
-                if stream.tell() > len(stream.getbuffer()):
-                    raise EOFError("Error skipping %d bytes" % to_skip)
+                if stream.tell() > len(stream.getbuffer()) and self.gz:
+                    # a GZIPInputStream skips by reading: it comes up short at the end of the data and skipBytesFully
+                    # gives up (KGJ:1036-1049); a FileInputStream seeks past the end without complaint and the read
+                    # below throws EOFException instead
+                    raise SkipError("Error skipping %d bytes" % to_skip)
                 assert stream.tell() == before + to_skip
                 cur_hash = needed
             raw = stream.read(24)
@@ -344,6 +355,11 @@ class Model:
                         Hit(otu_index, qk[2], avg_from_end, function_index, function_wt))
                     self.pos_count += 1                                 # KGJ:1014
             cur_hash += 1
+            new_fraction = int(10.0 * (float(cur_hash) / float(num_sigs)))      # KGJ:1017-1024 (Java double arithmetic, (int) truncates)
+            if new_fraction != fraction:
+                fraction = new_fraction
+                self.processed.append((fraction, self.kmers_found))
+                self.info_lines.append("Processed: %d%%, time=0 ms., found-so-far=%d" % (fraction * 10, self.kmers_found))
 
     # ---- KGJ:742-820
     def run(self, table_bytes: bytes, function_array, fasta_text: str) -> str:
@@ -376,6 +392,8 @@ class Model:
             self.info_lines.append("Kmers found: %d (pos-count=%d)" % (self.kmers_found, self.pos_count))
         except EOFError:
             self.info_lines.append("Error: null")           # KGJ:799-802: EOFException() has no message; swallowed
+        except SkipError as ex:
+            self.info_lines.append("Error: " + str(ex))     # IllegalStateException("Error skipping N bytes"), KGJ:1045-1047
         by_key = {}
         for cnt in hit_cnts:                                # KGJ:805-809 (later container wins)
             by_key[cnt["key"]] = cnt

@@ -33,7 +33,9 @@ class Result(C.Structure):
                 ("container_call_start", C.c_void_p), ("otu", C.c_void_p),
                 ("residues", C.c_int64), ("windows_valid", C.c_int64), ("slots_inspected", C.c_int64),
                 ("t_prepare", C.c_double), ("t_lookup", C.c_double), ("t_group", C.c_double),
-                ("lookup_aborted", C.c_int32), ("hit_events", C.c_void_p), ("container_tail_events", C.c_void_p)]
+                ("lookup_aborted", C.c_int32), ("hit_events", C.c_void_p), ("container_tail_events", C.c_void_p),
+                ("n_processed", C.c_int32), ("processed_tenth", C.c_int32 * 64), ("processed_found", C.c_int64 * 64),
+                ("kmers_found", C.c_int64), ("skip_failed_bytes", C.c_int64), ("read_eof", C.c_int32)]
 
 
 _lib = None
@@ -105,6 +107,10 @@ def run(table_image, seq, offsets, aa=False, order_constraint=False, min_hits=5,
         "residues": r.residues, "windows_valid": r.windows_valid, "slots_inspected": r.slots_inspected,
         "t_prepare": r.t_prepare, "t_lookup": r.t_lookup, "t_group": r.t_group,
         "lookup_aborted": bool(r.lookup_aborted),
+        # literal merge-join only (lookup_mode 0): the "Processed: NN%" lines (tenth, found-so-far) in print order, kmersFound,
+        # and how the table stream failed (KGJ:1016-1049)
+        "processed": [(int(r.processed_tenth[i]), int(r.processed_found[i])) for i in range(r.n_processed)],
+        "kmers_found": int(r.kmers_found), "skip_failed_bytes": int(r.skip_failed_bytes), "read_eof": bool(r.read_eof),
     }
     lib.kgo_result_free(C.byref(r))
     return out

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-INFO = ("Temp. directory: ", "Preparation time: ", "Kmer-table info: ", "Kmers found: ", "Error: ", "Lookup time: ", "Grouping time: ")
+INFO = ("Temp. directory: ", "Preparation time: ", "Kmer-table info: ", "Processed: ", "Kmers found: ", "Error: ", "Lookup time: ", "Grouping time: ")
 
 CASES = [  # (dna, order_constraint, min_hits, max_gap, min_weighted_hits)
     (True, False, 3, 200, 0),
@@ -116,12 +116,16 @@ def test_front_ends_print_the_debug_stream(case, tmp_path):
     for name in ("py.txt", "cli.txt"):
         got, info = _strip_info((tmp_path / name).read_text())
         assert got == want, name
-        # the lookup ends with "Kmers found: N (pos-count=M)" or, when a query walks off the end of the table, with the
-        # swallowed EOFException's "Error: null" (KGJ:797-802, 1031-1033): whichever the literal model prints
-        assert [ln.split(":")[0] for ln in info] == ["Temp. directory", "Preparation time", "Kmer-table info",
-                                                     want_info[1].split(":")[0], "Lookup time", "Grouping time"], name
+        # the lookup prints "Kmer-table info", a "Processed: NN%, time=.., found-so-far=K" line per tenth of the table its
+        # merge-join visits (KGJ:1016-1025) and ends with "Kmers found: N (pos-count=M)" or, when a query walks off the end
+        # of the table, with the swallowed EOFException's "Error: null" (KGJ:797-802, 1031-1033): whatever the literal
+        # model prints, in its order (the times aside)
+        import re
+        timeless = [re.sub(r"time=\d+ ms\.", "time=0 ms.", ln.rstrip("\n")) for ln in info]
+        assert timeless[2:-2] == want_info, (name, timeless, want_info)
+        assert [ln.split(":")[0] for ln in info[:2] + info[-2:]] == ["Temp. directory", "Preparation time", "Lookup time", "Grouping time"], name
         assert "Kmer-table info: numSigs=1009, entrySize=24, version=1\n" in info, name
-        assert [ln.rstrip("\n") for ln in info[2:4]] == want_info, name          # incl. "Kmers found: N (pos-count=M)"
+        assert sum(ln.startswith("Processed: ") for ln in info) >= 5, info
         assert info[0] == "Temp. directory: " + os.path.realpath("/tmp") + "\n", name
 
 
@@ -142,7 +146,12 @@ def test_kmers_found_line_from_hit_records(oracle, case):
             for s in range(len(off) - 1)]
     vals = np.concatenate(vals)
     if o["lookup_aborted"]:              # a query walked off the end of this small table: the reference reports the EOF
-        assert info[1] == "Error: null"
+        assert info[-1] == "Error: null"
     else:
-        assert info[1] == "Kmers found: %d (pos-count=%d)" % (len(np.unique(vals)), len(vals))
+        assert info[-1] == "Kmers found: %d (pos-count=%d)" % (len(np.unique(vals)), len(vals))
+        assert o["kmers_found"] == len(np.unique(vals))
+    # the "Processed" lines of the Python model and of the C oracle's literal merge-join (KGJ:1016-1025)
+    assert [ln for ln in info if ln.startswith("Processed: ")] == \
+        ["Processed: %d%%, time=0 ms., found-so-far=%d" % (10 * f, k) for f, k in o["processed"]]
+    assert len(o["processed"]) >= 5
     assert len(np.unique(vals)) < len(vals)          # the fixture repeats k-mers: N != M

@@ -1,0 +1,146 @@
+"""KG_F_PROGRESS: what the reference's table stream reports while its merge-join runs -- one "Processed: NN%, time=..,
+found-so-far=K" line per tenth of the table in which a slot is visited (KGJ:1016-1025), kmersFound (KGJ:1004-1006, 1031-1033)
+-- and how it fails on a table stream shorter than numSigs records (EOFException behind a read, KGJ:1097-1126, or "Error
+skipping N bytes" when a GZIPInputStream cannot skip to the next home slot, KGJ:1036-1049).  The HIP library notes the walks of
+all queries; checked here against the literal merge-join of the C oracle, through every scan strategy, and through both front
+ends on .gz and plain table files."""
+import gzip
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _lines(pr):
+    return [(f, pr["found_upto"][f]) for f in range(1, 11) if pr["first_visited"][f] >= 0]
+
+
+def _workload(seed, num_sigs, load, n_contigs, contig_len, dna=True):
+    from kmergutsjava_amd import synth
+    from helpers import plant
+    rec, placed, keys = synth.random_table(num_sigs, load, seed)
+    img = synth.table_image(rec)
+    if dna:
+        seq, off = synth.dna_uniform_config(n_contigs, contig_len, seed + 1)
+        sb = plant(seq.numpy().tobytes(), off, keys.tolist(), every=61)
+    else:
+        lens = np.full(n_contigs, contig_len, dtype=np.int64)
+        off = synth.offsets_of(lens)
+        sb = plant(synth.random_protein(int(off[-1]), seed + 1).numpy().tobytes(), off, keys.tolist(), every=23, dna=False)
+    return img, sb, off, rec
+
+
+@pytest.mark.parametrize("strategy", ["direct", "partitioned"])
+@pytest.mark.parametrize("case", [(31, 1009, 0.6, 5, 1500, True), (32, 50021, 0.9, 12, 4000, True), (33, 200003, 0.5, 40, 3000, False),
+                                  (34, 3_000_017, 0.5, 30, 200_000, True)])
+def test_progress_equals_the_literal_merge_join(oracle, monkeypatch, strategy, case):
+    from kmergutsjava_amd import hotpath
+    from kmergutsjava_amd.kmer_guts_java import hit_kmer_values
+    seed, num_sigs, load, n, ln, dna = case
+    img, sb, off, rec = _workload(seed, num_sigs, load, n, ln, dna)
+    monkeypatch.setenv("KG_PARTITION", "0" if strategy == "direct" else "1")
+    ora = oracle.run(img, sb, off, aa=not dna, lookup_mode=0, min_hits=2)
+    with hotpath.SignatureTable.from_bytes(img) as tab, tab.scan(sb, off, hotpath.Params(aa=not dna, min_hits=2, progress=True)) as r:
+        assert r.stats["partitioned"] == (0 if strategy == "direct" else 1)
+        assert r.hits().tobytes() == ora["hits"].tobytes() and r.calls().tobytes() == ora["calls"].tobytes()
+        pr = r.progress()
+        assert _lines(pr) == ora["processed"], (pr, ora["processed"])
+        assert pr["kmers_found"] == ora["kmers_found"] and pr["stream_slots"] == num_sigs and pr["first_beyond"] == -1
+        assert bool(pr["walk_ran_off"]) == ora["read_eof"] == bool(r.stats["lookup_ran_off"])
+        assert len(ora["processed"]) >= (9 if num_sigs < 1_000_000 else 5)
+        # the slot of every hit record: the table's record there carries the k-mer behind the hit
+        slots, hits, chs = r.hit_slots(), r.hits(), r.container_hit_start()
+        per = 6 if dna else 1
+        vals = np.concatenate([hit_kmer_values(sb[off[s]:off[s + 1]], not dna,
+                                               [hits["from0InProt"][chs[c]:chs[c + 1]] for c in range(s * per, s * per + per)])
+                               for s in range(len(off) - 1)])
+        keys = (rec[:, 1].numpy().astype(np.int64) << 32) | (rec[:, 0].numpy().astype(np.int64) & 0xFFFFFFFF)
+        assert len(slots) == len(vals) > 50 and np.array_equal(keys[slots], vals)
+        assert len(np.unique(slots)) == pr["kmers_found"]
+    # without the flag: no progress, and the accessors say so
+    with hotpath.SignatureTable.from_bytes(img) as tab, tab.scan(sb, off, hotpath.Params(aa=not dna, min_hits=2)) as r:
+        with pytest.raises(Exception):
+            r.progress()
+
+
+@pytest.mark.parametrize("strategy", ["direct", "partitioned"])
+def test_short_table_streams(oracle, monkeypatch, strategy):
+    """A table file cut behind record k: queries whose home slot lies behind the end are never looked up; the merge-join
+    fails either at a read (a walk reaches the end: EOFException) or at the skip to the first such home slot."""
+    from kmergutsjava_amd import hotpath
+    img, sb, off, rec = _workload(41, 50021, 0.5, 10, 5000)
+    monkeypatch.setenv("KG_PARTITION", "0" if strategy == "direct" else "1")
+    seen = set()
+    for cut in (50021 - 1, 40000, 25013, 25014, 25020, 12000, 300):
+        short = img[:24 + 24 * cut]
+        ora = oracle.run(short, sb, off, lookup_mode=0, min_hits=2)
+        with hotpath.SignatureTable.from_bytes(short) as tab, tab.scan(sb, off, hotpath.Params(min_hits=2, progress=True)) as r:
+            assert r.hits().tobytes() == ora["hits"].tobytes()
+            pr = r.progress()
+            assert pr["stream_slots"] == cut and _lines(pr) == ora["processed"], (cut, pr, ora["processed"])
+            assert pr["kmers_found"] == ora["kmers_found"]
+            # the first failure: a read behind the last record (a walk ran off, or nothing is left to skip) or the skip
+            if ora["read_eof"]:
+                assert pr["walk_ran_off"] == 1 or (pr["first_beyond"] >= 0 and pr["first_beyond"] == pr["last_visited"] + 1), (cut, pr)
+                seen.add("eof")
+            elif ora["skip_failed_bytes"] >= 0:
+                assert pr["walk_ran_off"] == 0 and 24 * (pr["first_beyond"] - (pr["last_visited"] + 1)) == ora["skip_failed_bytes"], (cut, pr)
+                seen.add("skip")
+            else:
+                assert pr["walk_ran_off"] == 0 and pr["first_beyond"] == -1
+                seen.add("none")
+    assert {"eof", "skip"} <= seen, seen
+
+
+def _info_lines(text):
+    return [re.sub(r"time=\d+ ms\.", "time=0 ms.", ln) for ln in text.splitlines()
+            if ln.startswith(("Processed: ", "Error: ", "Kmers found: "))]
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_front_ends_print_the_lookups_info_lines(tmp_path, gz):
+    """Both front ends, report into a file (info lines on stdout, KGJ:891-898) and with -d (info lines in the report too),
+    on a complete table and on one cut short, plain and .gz: the lines of the literal Python model."""
+    from kmergutsjava_amd import synth, build, KmerGutsJava
+    from oracle import kgj_model as M
+    from helpers import plant
+    rec, placed, keys = synth.random_table(50021, 0.5, 51)
+    img = synth.table_image(rec)
+    seq, off = synth.dna_uniform_config(6, 4000, 52)
+    sb = plant(seq.numpy().tobytes(), off, keys.tolist(), every=61)
+    fa = "".join(">c%d\n%s\n" % (k, sb[off[k]:off[k + 1]].decode()) for k in range(len(off) - 1))
+    (tmp_path / "q.fa").write_text(fa)
+    fn = ["function %d" % i for i in range(1000)]
+    cli = build.build_cli()
+    kinds = set()
+    for name, image in (("whole", img), ("cut", img[:24 + 24 * 30000]), ("cut2", img[:24 + 24 * 2000])):
+        d = tmp_path / (name + ("_gz" if gz else ""))
+        synth.write_data_dir(str(d), image, 1000, gz=gz)
+        m = M.Model(min_hits=2, debug=True, gz=gz)
+        m.run(image, fn, fa)
+        want = [ln for ln in m.info_lines if ln.startswith(("Processed: ", "Error: ", "Kmers found: "))]
+        assert sum(ln.startswith("Processed: ") for ln in want) >= 1
+        kinds.update(ln.split(" ")[1] for ln in want if ln.startswith("Error: "))
+        args = ["-D", str(d), "-q", str(tmp_path / "q.fa"), "-m", "2", "-d"]
+        out = subprocess.run([cli] + args + ["-o", str(tmp_path / "cli.txt")], check=True, capture_output=True, text=True).stdout
+        assert _info_lines(out) == [ln for ln in want if not ln.startswith("Kmers found")], (name, out, want)     # stdout: printInfoLine only
+        assert _info_lines((tmp_path / "cli.txt").read_text()) == want, name
+        KmerGutsJava.main(args + ["-o", str(tmp_path / "py.txt")])
+        assert _info_lines((tmp_path / "py.txt").read_text()) == want, name
+        # several batches (the CLI's test hook): the same lines, the distinct k-mers counted over all of them
+        out = subprocess.run([cli] + args + ["-o", str(tmp_path / "cli2.txt")], check=True, capture_output=True, text=True,
+                             env=dict(os.environ, KG_CLI_BATCH_CHARS="9000")).stdout
+        assert _info_lines((tmp_path / "cli2.txt").read_text()) == want, name
+        keep = KmerGutsJava.MAX_BATCH_CHARS
+        try:
+            KmerGutsJava.MAX_BATCH_CHARS = 9000
+            KmerGutsJava.main(args + ["-o", str(tmp_path / "py2.txt")])
+        finally:
+            KmerGutsJava.MAX_BATCH_CHARS = keep
+        assert _info_lines((tmp_path / "py2.txt").read_text()) == want, name
+        assert (tmp_path / "py2.txt").read_text().count("OTU-COUNTS") == 6
+    assert ("Error" in kinds) == gz and "null" in kinds, kinds          # "Error: Error skipping N bytes" only through gzip

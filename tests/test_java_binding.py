@@ -78,6 +78,22 @@ def test_structures_match_the_c_layout():
         assert order == [n for n, _ in cf], cname + ": setFieldOrder"
 
 
+def test_progress_structure_with_its_array_field():
+    """kg_progress has an int64[11] array in front: long[] of 11 in JNA, then the scalar fields in the C order."""
+    h = _strip_comments(HDR)
+    body = re.search(r"typedef struct kg_progress \{(.*?)\} kg_progress;", h, flags=re.S).group(1)
+    c_fields = [re.sub(r"\[\d+\]", "", d.split()[-1]) for d in body.split(";") if d.strip()]
+    assert re.search(r"int64_t\s+first_visited\[11\]", body)
+    j = _strip_comments(JAVA)
+    jb = re.search(r"class KgProgress extends Structure \{(.*?)\n    \}", j, flags=re.S).group(1)
+    assert re.search(r"public\s+long\[\]\s+first_visited\s*=\s*new\s+long\[11\]", jb)
+    assert re.search(r"int64_t\s+found_upto\[11\]", body) and re.search(r"public\s+long\[\]\s+found_upto\s*=\s*new\s+long\[11\]", jb)
+    order = re.findall(r'"([a-z_0-9]+)"', re.search(r"setFieldOrder\(new String\[\]\s*\{(.*?)\}\)", jb, flags=re.S).group(1))
+    assert order == c_fields == ["first_visited", "last_visited", "first_beyond", "walk_ran_off", "stream_slots", "found_upto", "kmers_found"]
+    from kmergutsjava_amd import _native
+    assert [n for n, _ in _native.KgProgress._fields_] == c_fields
+
+
 def test_targets_the_jna_level_the_reference_ships():
     assert "getFieldOrder" not in _strip_comments(JAVA), "getFieldOrder() does not exist in jna-3.4.0 (reference build.xml:27)"
     assert "java.util.List" not in JAVA and "Arrays.asList" not in JAVA
