@@ -159,8 +159,9 @@ typedef struct kg_progress {
     int64_t last_visited;        /* the last slot visited, -1 when none                                                           */
     int64_t first_beyond;        /* the smallest home slot of a query k-mer at or behind the END of the record stream (a table    */
                                  /* file shorter than numSigs records), -1 when none: the join has to skip to it and fails --     */
-                                 /* "Error skipping <24 x (first_beyond - last_visited - 1)> bytes" on a .gz stream               */
-                                 /* (KGJ:1036-1049), EOFException ("Error: null") on a plain file or when nothing is skipped      */
+                                 /* "Error skipping <24 x (first_beyond - last_visited - 1)> bytes" on a .gz stream when the slot */
+                                 /* lies BEHIND the end (first_beyond > stream_slots; KGJ:1036-1049), EOFException ("Error: null") */
+                                 /* at the read that follows the skip on a plain file, or when the slot is the end itself         */
     int64_t walk_ran_off;        /* 1: a walk reached the end of the stream undecided: EOFException before any such skip          */
     int64_t stream_slots;        /* records in the table stream (numSigs for a complete file)                                     */
     int64_t found_upto[11];      /* [f]: distinct k-mers found at slots <= first_visited[f] = the line's found-so-far (0 when the */

@@ -508,8 +508,9 @@ int main(int argc, char **argv)
                     // a table stream shorter than numSigs records and a query whose home slot lies behind its end: the join skips to
                     // it -- a GZIPInputStream comes up short ("Error skipping N bytes", KGJ:1036-1049), a plain file seeks past its
                     // end and the read behind it throws EOFException
+                    // (a home slot right AT the end of the stream is skipped to without trouble; the read there is what fails)
                     const long long skip = 24ll * (beyond - (last + 1));
-                    info(gz && skip > 0 ? "Error: Error skipping " + std::to_string(skip) + " bytes" : std::string("Error: null"));
+                    info(gz && beyond > prog[0].stream_slots ? "Error: Error skipping " + std::to_string(skip) + " bytes" : std::string("Error: null"));
                 } else if (o.debug) {
                     out.put("Kmers found: " + std::to_string(kmers_found) + " (pos-count=" + std::to_string(pos_count) + ")\n");
                 }

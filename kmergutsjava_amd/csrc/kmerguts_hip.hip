@@ -280,9 +280,10 @@ int table_finish(kg_table *t)
     hipLaunchKernelGGL(kg::build_tags_kernel, dim3(grid), dim3(256), 0, t->stream, t->d_entries, t->limit, n_tags,
                        (uint64_t)t->num_sigs, t->magic, t->d_tags, d_occ);
     HIP_TRY(hipGetLastError());
-    // the byte home index: what the one-level tag pass probes instead of the tags (KG_BIDX=0 leaves it out)
+    // the byte home index: what the tag pass probes instead of the tags, for every table the scatter pass applies to
+    // (KG_BIDX=0 switches it off per scan, not here: a table outlives the environment it was opened in)
     t->bidx_exact = (uint64_t)KG_MAX_ENCODED / (uint64_t)t->num_sigs + 1 <= kg::kBidxClasses;
-    if (t->m35 != 0 && t->limit > 0 && env_u32("KG_BIDX", 1u) != 0) {
+    if (t->m35 != 0 && t->limit > 0) {
         const uint64_t n_bidx = t->limit + kg::kTagPad;
         HIP_TRY(hipMalloc((void **)&t->d_bidx, n_bidx));
         const uint64_t wantb = (n_bidx + 255) / 256;

@@ -498,6 +498,7 @@ class KmerGutsJava:
         last = max(p["last_visited"] for p in progress)
         beyond = min([p["first_beyond"] for p in progress if p["first_beyond"] >= 0], default=-1)
         ran_off = any(p["walk_ran_off"] for p in progress)
+        stream_slots = progress[0]["stream_slots"]
         if len(progress) == 1:
             found_upto, kmers_found = progress[0]["found_upto"], progress[0]["kmers_found"]
         else:                                                     # a k-mer found in two batches counts once
@@ -516,8 +517,9 @@ class KmerGutsJava:
             # the table stream is shorter than numSigs records and a query's home slot lies behind its end: the join skips
             # to it -- a GZIPInputStream comes up short ("Error skipping N bytes", KGJ:1036-1049), a plain file seeks past
             # its end and the read behind it throws EOFException
+            # (a home slot right AT the end of the stream is skipped to without trouble; the read there is what fails)
             skip = 24 * (beyond - (last + 1))
-            self._info("Error: Error skipping %d bytes" % skip if gz and skip > 0 else "Error: null", pw, stdout)
+            self._info("Error: Error skipping %d bytes" % skip if gz and beyond > stream_slots else "Error: null", pw, stdout)
         elif self.debug:                                          # KGJ:1031-1033
             pw.write("Kmers found: %d (pos-count=%d)\n" % (kmers_found, pos_count))
 

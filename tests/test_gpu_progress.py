@@ -85,10 +85,11 @@ def test_short_table_streams(oracle, monkeypatch, strategy):
             assert pr["kmers_found"] == ora["kmers_found"]
             # the first failure: a read behind the last record (a walk ran off, or nothing is left to skip) or the skip
             if ora["read_eof"]:
-                assert pr["walk_ran_off"] == 1 or (pr["first_beyond"] >= 0 and pr["first_beyond"] == pr["last_visited"] + 1), (cut, pr)
+                assert pr["walk_ran_off"] == 1 or pr["first_beyond"] == cut, (cut, pr)       # (a home slot AT the end: skipped to, then read)
                 seen.add("eof")
             elif ora["skip_failed_bytes"] >= 0:
-                assert pr["walk_ran_off"] == 0 and 24 * (pr["first_beyond"] - (pr["last_visited"] + 1)) == ora["skip_failed_bytes"], (cut, pr)
+                assert pr["walk_ran_off"] == 0 and pr["first_beyond"] > cut, (cut, pr)
+                assert 24 * (pr["first_beyond"] - (pr["last_visited"] + 1)) == ora["skip_failed_bytes"], (cut, pr)
                 seen.add("skip")
             else:
                 assert pr["walk_ran_off"] == 0 and pr["first_beyond"] == -1
@@ -123,7 +124,7 @@ def test_front_ends_print_the_lookups_info_lines(tmp_path, gz):
         m = M.Model(min_hits=2, debug=True, gz=gz)
         m.run(image, fn, fa)
         want = [ln for ln in m.info_lines if ln.startswith(("Processed: ", "Error: ", "Kmers found: "))]
-        assert sum(ln.startswith("Processed: ") for ln in want) >= 1
+        assert sum(ln.startswith("Processed: ") for ln in want) == {"whole": 9, "cut": 5, "cut2": 0}[name], want   # (whole: the last slot is not visited; 2000 records: all in tenth 0)
         kinds.update(ln.split(" ")[1] for ln in want if ln.startswith("Error: "))
         args = ["-D", str(d), "-q", str(tmp_path / "q.fa"), "-m", "2", "-d"]
         out = subprocess.run([cli] + args + ["-o", str(tmp_path / "cli.txt")], check=True, capture_output=True, text=True).stdout
