@@ -265,6 +265,9 @@ __global__ __launch_bounds__(kHThreads) void hit_partition_kernel(const kg_hit *
     }
 }
 
+// (One pass instead -- every record straight to its group's range through a cursor per group, the write-back L2 combining the
+//  24-byte stores -- was built and measured in round 4: byte-identical, stage 15.5 -> 15.95 ms, 125 Mbp shard 2.99 -> 3.19:
+//  profiles/r04_experiments.md.)
 // One workgroup per group of 2^gshift rows.  Dynamic LDS: (8 + 4) << gshift bytes, and with `staged` (8 + 4 + 8) << gshift
 // + kPlaceOut * 24: the rows' geometry records are brought in with one coalesced read and the group's records are put in
 // order in LDS and leave as a flat stream of 8-byte words.  (Placed straight from the registers every record cost a gather
