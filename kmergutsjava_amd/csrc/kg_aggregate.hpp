@@ -181,9 +181,24 @@ struct EvMasks {
 // walks a container's pieces in order.
 constexpr uint32_t kNoPiece = 0xFFFFFFFFu;
 
+// PAIR pieces (round 4; dense inputs have no gaps: sequences assembled from signature k-mers, or a chromosome's coding regions):
+// the machine's state is also known, whatever came before, right behind the record p2 at which the pair rule fires (KGJ:503-508):
+// the list is processed and cut down to its last two members p1, p2 = two consecutive records of one function Y, currentFI = Y
+// (KGJ:441-449) -- exactly the state of a machine that starts with an empty list at p1.  The rule fires at p2 iff currentFI != Y,
+// and currentFI is the function of the latest ANCHOR before p1: a record that starts a list (first of its container, or
+// behind a gap) or repeats its predecessor's function (after such a record the current function is that record's, whether
+// the rule fired there or not).  So a piece may start at p1 when p1 itself is no anchor, p1 + 1 repeats its function without
+// a gap, and the latest anchor in the 256 records before p1 carries ANOTHER function.  Only in containers of fewer than
+// 39 000 records, where no list comes near the 39 998 cap (KGJ:496: near it the rule looks at records that were not appended).
+// The unit that runs into such a piece does at p1 what the pair rule does at p2 -- processSetOfHits on its list, to which p1, p2
+// would add no vote (their function is not the current one) -- and hands the record p2 its *_AFTER event bits.
+constexpr uint32_t kPairWindow = 256;
+constexpr uint32_t kPairMaxContainer = 39000;
+
 __global__ __launch_bounds__(256) void piece_starts_kernel(const kg_hit *__restrict__ hits, const int64_t *__restrict__ chs,
                                                            uint32_t n_hits, uint32_t pshift, int32_t max_gap,
-                                                           uint32_t *__restrict__ piece_start, uint32_t n_blocks)
+                                                           uint32_t *__restrict__ piece_start, uint8_t *__restrict__ piece_pair /* 1: a pair piece */,
+                                                           uint32_t n_blocks, uint32_t pairs_ok)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t u = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -211,15 +226,62 @@ __global__ __launch_bounds__(256) void piece_starts_kernel(const kg_hit *__restr
         const uint32_t lo = (uint32_t)chs[c], hi = (uint32_t)chs[c + 1];
         if (found - lo < blk / 2 || hi - found < blk / 2) found = kNoPiece;      // pieces of at least half a block
     }
-    if (lane == 0) piece_start[u] = found;
+    uint32_t pair = 0;
+    if (found == kNoPiece && pairs_ok && u > 0 && i0 < n_hits) {
+        const uint32_t c0 = hits[i0].container;
+        const uint32_t lo0 = (uint32_t)chs[c0], hi0 = (uint32_t)chs[c0 + 1];
+        if (hi0 - lo0 >= 2u * blk && hi0 - lo0 < kPairMaxContainer) {
+            const uint32_t w0 = i0 - lo0 > kPairWindow ? i0 - kPairWindow : lo0;          // the look-back starts here
+            const uint32_t span = min(256u, blk);                                            // p1 in [i0, i0 + span)
+            const uint32_t wend = min(min(i0 + span + 1u, hi0), n_hits);                     // records looked at: [w0, wend)
+            int32_t afi = 0;                                                                 // the latest anchor so far (uniform)
+            bool have = false, carry_eq = false, carry_start = false;
+            for (uint32_t b = w0; b < wend && found == kNoPiece; b += 64) {
+                const uint32_t i = b + (uint32_t)lane;
+                const bool in = i < wend;
+                int32_t fI = 0;
+                bool cstart = false, gapf = false, eqf = false;
+                if (in) {
+                    const kg_hit cur = hits[i];
+                    fI = cur.fI;
+                    cstart = i == lo0;
+                    if (!cstart) {
+                        const kg_hit prv = hits[i - 1];
+                        gapf = (int32_t)((uint32_t)prv.from0InProt + (uint32_t)max_gap) < cur.from0InProt;
+                        eqf = !gapf && prv.fI == cur.fI;
+                    }
+                }
+                const uint64_t am = __ballot(in && (cstart || gapf || eqf)), eqm = __ballot(eqf), stm = __ballot(cstart || gapf);
+                // the latest anchor before this lane's record: in this chunk, else the one carried in
+                const uint64_t below = am & ((1ull << lane) - 1ull);
+                const int al = below ? 63 - __builtin_clzll(below) : 0;
+                const int32_t lfi = __shfl(fI, al);
+                const bool phave = below ? true : have;
+                const int32_t pfi = below ? lfi : afi;
+                const bool prev_eq = lane ? ((eqm >> (lane - 1)) & 1ull) != 0 : carry_eq;
+                const bool prev_start = lane ? ((stm >> (lane - 1)) & 1ull) != 0 : carry_start;
+                // this record is p2 = the second of a run whose first record p1 = i - 1 is no anchor
+                const bool cand = eqf && !prev_eq && !prev_start && phave && pfi != fI && i >= i0 + 1u && i - 1u < i0 + span &&
+                                  i - 1u - lo0 >= blk / 2 && hi0 - (i - 1u) >= blk / 2;
+                const uint64_t cm = __ballot(cand);
+                if (cm) { found = b + (uint32_t)__builtin_ctzll(cm) - 1u; pair = 1; }
+                if (am) { const int last = 63 - __builtin_clzll(am); afi = rl(fI, last); have = true; }
+                carry_eq = (eqm >> 63) & 1ull;
+                carry_start = (stm >> 63) & 1ull;
+            }
+        }
+    }
+    if (lane == 0) { piece_start[u] = found; piece_pair[u] = (uint8_t)pair; }
 }
 
-__global__ void merge_before_kernel(const uint32_t *__restrict__ piece_start, const uint8_t *__restrict__ before_ev, uint32_t n_blocks,
-                                    uint8_t *ev, unsigned long long *n_pieces)
+__global__ void merge_before_kernel(const uint32_t *__restrict__ piece_start, const uint8_t *__restrict__ piece_pair,
+                                    const uint8_t *__restrict__ before_ev, uint32_t n_blocks, uint8_t *ev, unsigned long long *n_pieces)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ps = u < n_blocks ? piece_start[u] : kNoPiece;
-    if (ps != kNoPiece && before_ev[u]) ev[ps] |= before_ev[u];
+    // a gap piece: the *_BEFORE bits of its first record; a pair piece: the *_AFTER bits of its second record (where the pair
+    // rule fires in the reference)
+    if (ps != kNoPiece && before_ev[u]) ev[ps + (piece_pair[u] ? 1u : 0u)] |= before_ev[u];
     const unsigned long long m = __ballot(ps != kNoPiece);
     if (m && (threadIdx.x & 63) == 0) atomicAdd(n_pieces, (unsigned long long)__popcll(m));
 }
@@ -228,8 +290,8 @@ __global__ void merge_before_kernel(const uint32_t *__restrict__ piece_start, co
 // staging range.  Returns the number of CALLs; *tail_out = the container's tail event when the unit reached `end`.
 __device__ __forceinline__ uint32_t walk_unit(const kg_hit *__restrict__ hits, const AggParams &p, uint8_t *acc, uint8_t *vote,
                                               const uint32_t begin, const uint32_t end, const uint32_t c, kg_call *calls,
-                                              const uint32_t *__restrict__ piece_start, const uint32_t pshift, uint8_t *before_ev,
-                                              uint32_t *tail_out, bool *reached_end)
+                                              const uint32_t *__restrict__ piece_start, const uint8_t *__restrict__ piece_pair,
+                                              const uint32_t pshift, uint8_t *before_ev, uint32_t *tail_out, bool *reached_end)
 {
     const int lane = threadIdx.x & 63;
     uint32_t stopped_at = kNoPiece;
@@ -398,7 +460,20 @@ __device__ __forceinline__ uint32_t walk_unit(const kg_hit *__restrict__ hits, c
         if (stopped_at != kNoPiece) break;
     }
     uint32_t tail = 0;
-    if (stopped_at != kNoPiece) {
+    if (stopped_at != kNoPiece && piece_pair[stopped_at >> pshift]) {
+        // the next piece starts at the first record of a pair whose second record fires the pair rule (KGJ:503-508; see
+        // piece_starts_kernel): processSetOfHits on the list as it stands -- the pair's two records would be its last members and
+        // cast no vote -- after which the reference keeps exactly those two: the next piece's business.  The event bits go
+        // to the pair's second record.
+        uint32_t bits = 0;
+        if (s.cnt > 0) {
+            bits = KG_EV_RESET_AFTER | KG_EV_KEEP2_AFTER;
+            uint64_t tail_votes = 0;
+            if (process_set(hits, acc, vote, begin, p, s, pv, ppv, tail_votes, c, calls, false) & 1u) bits |= KG_EV_CALL_AFTER;
+            if ((tail_votes >> lane) & 1ull) vote[pv.base + lane] = 1;
+        }
+        if (lane == 0) before_ev[stopped_at >> pshift] = (uint8_t)bits;
+    } else if (stopped_at != kNoPiece) {
         // the next piece's first record lies behind a gap: what the gap rule does there (KGJ:477-484), no carry
         uint32_t bits = 0;
         if (s.cnt > 0) {
@@ -428,7 +503,8 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
                                                          uint32_t n_cont, AggParams p, uint8_t *acc, uint8_t *vote, uint8_t *tail_ev,
                                                          uint32_t *call_cnt, uint32_t *first_cnt, kg_call *staged /* [n_hits / minHits + 1] */,
                                                          uint32_t per_wave, uint32_t n_cwaves, const uint32_t *__restrict__ piece_start,
-                                                         uint32_t pshift, uint32_t n_pblocks, uint32_t *piece_cnt, uint8_t *before_ev)
+                                                         uint32_t pshift, uint32_t n_pblocks, uint32_t *piece_cnt, uint8_t *before_ev,
+                                                         const uint8_t *__restrict__ piece_pair)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t w = (uint32_t)uni((int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -441,8 +517,8 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
         const uint32_t end = (uint32_t)chs[c + 1];
         uint32_t tail;
         bool reached_end;
-        const uint32_t ncalls = walk_unit(hits, p, acc, vote, begin, end, c, staged + begin / (uint32_t)p.min_hits, piece_start, pshift,
-                                          before_ev, &tail, &reached_end);
+        const uint32_t ncalls = walk_unit(hits, p, acc, vote, begin, end, c, staged + begin / (uint32_t)p.min_hits, piece_start, piece_pair,
+                                          pshift, before_ev, &tail, &reached_end);
         if (lane == 0) {
             piece_cnt[u] = ncalls;
             if (ncalls) atomicAdd(&call_cnt[c], ncalls);
@@ -470,8 +546,8 @@ __global__ __launch_bounds__(256) void calls_wave_kernel(const kg_hit *__restric
         const uint32_t begin = (uint32_t)rl((int32_t)my_begin, ci), end = (uint32_t)rl((int32_t)my_end, ci);
         uint32_t tail;
         bool reached_end;
-        const uint32_t ncalls = walk_unit(hits, p, acc, vote, begin, end, c, staged + begin / (uint32_t)p.min_hits, piece_start, pshift,
-                                          before_ev, &tail, &reached_end);
+        const uint32_t ncalls = walk_unit(hits, p, acc, vote, begin, end, c, staged + begin / (uint32_t)p.min_hits, piece_start, piece_pair,
+                                          pshift, before_ev, &tail, &reached_end);
         if (lane == 0) {
             first_cnt[c] = ncalls;
             if (ncalls) atomicAdd(&call_cnt[c], ncalls);
@@ -581,14 +657,16 @@ __global__ __launch_bounds__(256) void otu_wave_kernel(const int32_t *__restrict
         const uint64_t m = __ballot(c0 + (uint32_t)lane < n_hits && c0 + (uint32_t)lane < i && vote[c0 + lane] != 0);
         return (c0 < n_hits ? voff[c0 >> 6] : voff[(n_hits + 63u) >> 6]) + (uint32_t)__popcll(m);
     };
+    // The five-entry buffer lives in the LANES 0..4 of the wave (round 4; in scalar registers before: ~100 dependent scalar
+    // instructions per vote, 0.83 of the 1.43 ms of aggregation on the high-density config and most of a single chromosome's):
+    // lane t holds entry t; a vote is one ballot (where is it?), one ballot (how far does it bubble?) and a rotate by DPP.
     for (uint32_t s = s_first; s < s_first + per_wave && s < n_seqs; s++) {
-        int32_t n = 0;
-        int32_t cnt[KG_OI_BUFSZ] = {0, 0, 0, 0, 0}, oi[KG_OI_BUFSZ] = {0, 0, 0, 0, 0};
+        int32_t n = 0;                                                      // (wave-uniform)
+        int32_t cnt = 0, oi = 0;                                            // lane t < n: entry t
         if (otu_init) {                                                     // the caller's oICounts (kg_aggregate_hits)
-            const kg_otu r0 = otu_init[s];
-            n = min(max(r0.n, 0), KG_OI_BUFSZ);
-#pragma unroll
-            for (int k = 0; k < KG_OI_BUFSZ; k++) { cnt[k] = r0.count[k]; oi[k] = r0.oI[k]; }
+            const kg_otu *r0 = otu_init + s;
+            n = uni(min(max(r0->n, 0), KG_OI_BUFSZ));
+            if (lane < KG_OI_BUFSZ) { cnt = r0->count[lane]; oi = r0->oI[lane]; }
         }
         const uint32_t vb = voter_index((uint32_t)chs[(uint64_t)s * per]), ve = voter_index((uint32_t)chs[(uint64_t)(s + 1) * per]);
         int32_t n_o = vb + (uint32_t)lane < ve ? vlist[vb + lane] : 0;
@@ -607,39 +685,40 @@ __global__ __launch_bounds__(256) void otu_wave_kernel(const int32_t *__restrict
                 heads &= heads - 1;
                 const int32_t r = (heads ? __builtin_ctzll(heads) : nv) - k;
                 const int32_t ok = rl(o, k);
-                if (n > 0 && oi[0] == ok) { cnt[0] += r; continue; }    // the leading entry: found at 0, nothing to bubble past
-                int j = n;                                              // KGJ:416-417 linear search
-#pragma unroll
-                for (int t = KG_OI_BUFSZ - 1; t >= 0; t--)
-                    if (t < n && oi[t] == ok) j = t;
-                if (j == n) {                                           // KGJ:418-427
-                    if (n == KG_OI_BUFSZ) j--; else n++;
-#pragma unroll
-                    for (int t = 0; t < KG_OI_BUFSZ; t++)
-                        if (t == j) { oi[t] = ok; cnt[t] = r; }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < KG_OI_BUFSZ; t++)
-                        if (t == j) cnt[t] += r;
+                const uint64_t at = __ballot(lane < n && oi == ok);         // KGJ:416-417 linear search (entries are distinct)
+                int j;
+                if (at) {
+                    j = __builtin_ctzll(at);
+                    if (lane == j) cnt += r;
+                    if (j == 0) continue;                                   // the leading entry: nothing to bubble past
+                } else {                                                    // KGJ:418-427: append, or overwrite the last entry
+                    if (n == KG_OI_BUFSZ) j = KG_OI_BUFSZ - 1; else j = n++;
+                    if (lane == j) { oi = ok; cnt = r; }
+                    if (j == 0) continue;
                 }
-#pragma unroll
-                for (int t = KG_OI_BUFSZ - 1; t >= 1; t--) {            // KGJ:432-437 bubble toward the front
-                    if (j == t && cnt[t - 1] <= cnt[t]) {
-                        int32_t tc = cnt[t - 1], to = oi[t - 1];
-                        cnt[t - 1] = cnt[t]; oi[t - 1] = oi[t];
-                        cnt[t] = tc; oi[t] = to;
-                        j = t - 1;
-                    }
+                // KGJ:432-437: toward the front while the neighbour in front does not have MORE: past the run of entries with
+                // cnt <= mine that ends right in front of j (for a buffer this replay built itself the counts never increase
+                // towards the back, but a caller's oICounts may hold anything)
+                const int32_t cj = rl(cnt, j);
+                const uint32_t le = (uint32_t)__ballot(lane < j && cnt <= cj);          // bits 0 .. j-1
+                const uint32_t gt = ~le & ((1u << j) - 1u);
+                const int p = gt ? 32 - __builtin_clz(gt) : 0;                           // new place of entry j
+                if (p < j) {
+                    const int32_t oj = rl(oi, j);
+                    // the neighbour in front through DPP (row_shr:1; the five lanes share a row): no LDS round trip
+                    const int32_t pc = __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xF, 0xF, false);
+                    const int32_t po = __builtin_amdgcn_update_dpp(0, oi, 0x111, 0xF, 0xF, false);
+                    if (lane > p && lane <= j) { cnt = pc; oi = po; }
+                    else if (lane == p) { cnt = cj; oi = oj; }
                 }
             }
         }
-        if (lane == 0) {
-            kg_otu r;
-            r.n = n;
-#pragma unroll
-            for (int k = 0; k < KG_OI_BUFSZ; k++) { r.count[k] = k < n ? cnt[k] : 0; r.oI[k] = k < n ? oi[k] : 0; }
-            otu[s] = r;
+        // lane t writes entry t (zeros behind n), lane 0 the count as well
+        if (lane < KG_OI_BUFSZ) {
+            otu[s].count[lane] = lane < n ? cnt : 0;
+            otu[s].oI[lane] = lane < n ? oi : 0;
         }
+        if (lane == 0) otu[s].n = n;
     }
 }
 

@@ -673,7 +673,7 @@ int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc
                             n_hits > (2ull << pshift) && env_u32("KG_AGG_PIECES", 1u) != 0;
         const uint32_t n_pblocks = pieces ? (uint32_t)((n_hits + (1ull << pshift) - 1) >> pshift) : 0u;
         uint32_t *d_pstart = nullptr, *d_pcnt = nullptr;
-        uint8_t *d_before = nullptr;
+        uint8_t *d_before = nullptr, *d_ppair = nullptr;
         t->h_pin[kPinCalls] = 0;
         t->h_pin[kPinPieces] = 0;
         {   // clears: the containers' CALL totals (units add to them), the pieces' counts and hand-over bytes
@@ -685,6 +685,7 @@ int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc
                 if ((rc = sc.get(&d_pstart, (size_t)n_pblocks + 1))) return rc;
                 if ((rc = sc.get(&d_pcnt, (size_t)n_pblocks + 1))) return rc;
                 if ((rc = sc.get(&d_before, ((size_t)n_pblocks + 4) & ~(size_t)3))) return rc;
+                if ((rc = sc.get(&d_ppair, ((size_t)n_pblocks + 4) & ~(size_t)3))) return rc;
                 cl.p[cl.n] = d_pcnt; cl.words[cl.n++] = (uint64_t)n_pblocks + 1;
                 cl.p[cl.n] = reinterpret_cast<uint32_t *>(d_before); cl.words[cl.n++] = ((uint64_t)n_pblocks + 4) / 4;
             }
@@ -696,7 +697,7 @@ int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc
         }
         if (pieces)
             hipLaunchKernelGGL(kg::piece_starts_kernel, dim3((n_pblocks + 3) / 4), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
-                               (uint32_t)n_hits, pshift, ap.max_gap, d_pstart, n_pblocks);
+                               (uint32_t)n_hits, pshift, ap.max_gap, d_pstart, d_ppair, n_pblocks, env_u32("KG_AGG_PAIRS", 1u));
         // one wave per unit: the containers' first pieces (several consecutive containers per wave when there are millions of
         // them: short reads), then one per block of hits[] that a later piece may start in
         const uint32_t cpw = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, n_cont / (1u << 17)));
@@ -704,9 +705,9 @@ int aggregate_stage(kg_table *t, const kg_params *p, kg_result *res, Scratch &sc
         if (n_cont) {
             hipLaunchKernelGGL(kg::calls_wave_kernel, dim3((n_cwaves + n_pblocks + 3) / 4), dim3(256), 0, t->stream, res->d_hits, res->d_chs,
                                (uint32_t)n_cont, ap, d_acc, d_vote, res->d_tail_ev, d_ccnt, d_first, d_staged, cpw, n_cwaves, d_pstart,
-                               pshift, n_pblocks, d_pcnt, d_before);
+                               pshift, n_pblocks, d_pcnt, d_before, d_ppair);
             if (pieces)
-                hipLaunchKernelGGL(kg::merge_before_kernel, dim3((n_pblocks + 255) / 256), dim3(256), 0, t->stream, d_pstart, d_before,
+                hipLaunchKernelGGL(kg::merge_before_kernel, dim3((n_pblocks + 255) / 256), dim3(256), 0, t->stream, d_pstart, d_ppair, d_before,
                                    n_pblocks, res->d_ev, (unsigned long long *)(d_totals + 6));
             HIP_TRY(hipGetLastError());
         }

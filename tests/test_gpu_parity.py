@@ -292,6 +292,34 @@ def test_long_containers_in_pieces(hp, oracle, shift, monkeypatch):
             monkeypatch.delenv("KG_AGG_PIECES")
 
 
+@pytest.mark.parametrize("shift", [6, 7, 9])
+@pytest.mark.parametrize("dna", [True, False])
+def test_dense_containers_in_pair_pieces(hp, oracle, shift, dna, monkeypatch):
+    """Dense input has no gaps to cut a long container at; it is cut where the pair rule fires with a known outcome instead
+    (KGJ:503-508, 441-449; kg_aggregate.hpp piece_starts_kernel): contigs / proteins assembled from signature k-mers in
+    same-function runs of 1..12 (thousands of hits per container, a pair-rule reset every dozen), small blocks (many pieces)
+    and the production block size, against the oracle -- event bytes included -- and against the same scan without pair
+    pieces; several parameter sets (minHits decides which of the fired sets print a CALL)."""
+    from kmergutsjava_amd import synth
+    seq, off, rec, keys = synth.high_density_config(5, 2500 if dna else 3000, 20011, 6000, seed=611, dna=dna)
+    img = _img(rec)
+    sb = seq.numpy().tobytes()
+    monkeypatch.setenv("KG_AGG_BLOCK_SHIFT", str(shift))
+    with hp.SignatureTable.from_bytes(img) as tab:
+        for kw in (dict(), dict(min_hits=2), dict(min_hits=3, min_weighted_hits=2, max_gap=30), dict(min_hits=8, max_gap=1000)):
+            ora = oracle.run(img, sb, off, aa=not dna, lookup_mode=1, **kw)
+            assert np.diff(ora["container_hit_start"]).max() > 2000 and len(ora["calls"]) > 100
+            with tab.scan(sb, off, hp.Params(aa=not dna, **kw)) as r:
+                assert_same_records(r, ora, "pair pieces shift=%d dna=%s %s" % (shift, dna, kw))
+                pieces = r.stats["agg_pieces"]
+                assert pieces >= (40 if shift < 9 else 8), pieces
+            monkeypatch.setenv("KG_AGG_PAIRS", "0")
+            with tab.scan(sb, off, hp.Params(aa=not dna, **kw)) as r:
+                assert_same_records(r, ora, "no pair pieces %s" % kw)
+                assert r.stats["agg_pieces"] < pieces
+            monkeypatch.delenv("KG_AGG_PAIRS")
+
+
 def test_otu_votes_in_runs(hp, oracle):
     """The OTU stage replays consecutive voters with the same otuIndex as one step (KGJ:413-439 applied r times = count + r
     and one bubble pass).  Tables whose signatures name very few OTUs, unevenly, so that the voters come in long runs and
