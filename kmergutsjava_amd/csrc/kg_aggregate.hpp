@@ -662,10 +662,12 @@ __global__ __launch_bounds__(256) void otu_wave_kernel(const int32_t *__restrict
     // lane t holds entry t; a vote is one ballot (where is it?), one ballot (how far does it bubble?) and a rotate by DPP.
     for (uint32_t s = s_first; s < s_first + per_wave && s < n_seqs; s++) {
         int32_t n = 0;                                                      // (wave-uniform)
+        uint32_t nmask = 0;                                                 // (1 << n) - 1: the lanes that hold an entry
         int32_t cnt = 0, oi = 0;                                            // lane t < n: entry t
         if (otu_init) {                                                     // the caller's oICounts (kg_aggregate_hits)
             const kg_otu *r0 = otu_init + s;
             n = uni(min(max(r0->n, 0), KG_OI_BUFSZ));
+            nmask = (1u << n) - 1u;
             if (lane < KG_OI_BUFSZ) { cnt = r0->count[lane]; oi = r0->oI[lane]; }
         }
         const uint32_t vb = voter_index((uint32_t)chs[(uint64_t)s * per]), ve = voter_index((uint32_t)chs[(uint64_t)(s + 1) * per]);
@@ -680,37 +682,43 @@ __global__ __launch_bounds__(256) void otu_wave_kernel(const int32_t *__restrict
             // a new entry likewise: inserted with 1 and raised r - 1 times = inserted with r).
             const int32_t before = __shfl_up(o, 1);
             uint64_t heads = __ballot(lane < nv && (lane == 0 || o != before));
+            // a head lane's run length, computed by all lanes at once (one readlane per step instead of five scalar instructions)
+            const uint64_t above = lane < 63 ? heads >> (lane + 1) : 0ull;
+            const int32_t rlen = above ? __builtin_ctzll(above) + 1 : nv - lane;
+            // With one wave per SIMD every instruction of a step is on the clock (config 5: 3 300 steps per sequence, nothing
+            // else to run): ballots of ONE compare each, masked with scalar masks (a ballot of "lane < n && ..." costs two more
+            // VALU instructions); the lanes behind n hold nothing that is ever read, so the count is raised wherever the
+            // otuIndex matches; and the common outcome of the bubble -- the entry in front has more, nothing moves -- is one
+            // bit test.
             while (heads) {
                 const int k = __builtin_ctzll(heads);
                 heads &= heads - 1;
-                const int32_t r = (heads ? __builtin_ctzll(heads) : nv) - k;
-                const int32_t ok = rl(o, k);
-                const uint64_t at = __ballot(lane < n && oi == ok);         // KGJ:416-417 linear search (entries are distinct)
+                const int32_t ok = rl(o, k), r = rl(rlen, k);
+                const bool same = oi == ok;
+                const uint64_t at = __ballot(same) & nmask;                 // KGJ:416-417 linear search (entries are distinct)
                 int j;
                 if (at) {
                     j = __builtin_ctzll(at);
-                    if (lane == j) cnt += r;
-                    if (j == 0) continue;                                   // the leading entry: nothing to bubble past
+                    cnt += same ? r : 0;
                 } else {                                                    // KGJ:418-427: append, or overwrite the last entry
-                    if (n == KG_OI_BUFSZ) j = KG_OI_BUFSZ - 1; else j = n++;
+                    if (n == KG_OI_BUFSZ) j = KG_OI_BUFSZ - 1; else { j = n++; nmask = nmask * 2u + 1u; }
                     if (lane == j) { oi = ok; cnt = r; }
-                    if (j == 0) continue;
                 }
+                if (j == 0) continue;                                       // the leading entry: nothing to bubble past
                 // KGJ:432-437: toward the front while the neighbour in front does not have MORE: past the run of entries with
                 // cnt <= mine that ends right in front of j (for a buffer this replay built itself the counts never increase
                 // towards the back, but a caller's oICounts may hold anything)
                 const int32_t cj = rl(cnt, j);
-                const uint32_t le = (uint32_t)__ballot(lane < j && cnt <= cj);          // bits 0 .. j-1
-                const uint32_t gt = ~le & ((1u << j) - 1u);
-                const int p = gt ? 32 - __builtin_clz(gt) : 0;                           // new place of entry j
-                if (p < j) {
-                    const int32_t oj = rl(oi, j);
-                    // the neighbour in front through DPP (row_shr:1; the five lanes share a row): no LDS round trip
-                    const int32_t pc = __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xF, 0xF, false);
-                    const int32_t po = __builtin_amdgcn_update_dpp(0, oi, 0x111, 0xF, 0xF, false);
-                    if (lane > p && lane <= j) { cnt = pc; oi = po; }
-                    else if (lane == p) { cnt = cj; oi = oj; }
-                }
+                const uint32_t more = (uint32_t)__ballot(cnt > cj);          // (bits at and behind j: not looked at)
+                if ((more >> (j - 1)) & 1u) continue;                        // the neighbour in front has more: entry j stays
+                const uint32_t gt = more & ((1u << j) - 1u);
+                const int p = gt ? 32 - __builtin_clz(gt) : 0;               // new place of entry j (< j)
+                const int32_t oj = rl(oi, j);
+                // the neighbour in front through DPP (row_shr:1; the five lanes share a row): no LDS round trip
+                const int32_t pc = __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xF, 0xF, false);
+                const int32_t po = __builtin_amdgcn_update_dpp(0, oi, 0x111, 0xF, 0xF, false);
+                if (lane > p && lane <= j) { cnt = pc; oi = po; }
+                else if (lane == p) { cnt = cj; oi = oj; }
             }
         }
         // lane t writes entry t (zeros behind n), lane 0 the count as well
