@@ -764,7 +764,8 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
     uint32_t *__restrict__ counts,
     uint32_t *__restrict__ block_stage_base, kg_hit *__restrict__ stage, unsigned long long *cursor, uint64_t stage_cap,
     uint32_t stage_chunk, unsigned long long *ctr,
-    Progress *prog /* KG_F_PROGRESS (COUNTERS kernels), else null */, uint32_t *__restrict__ stage_slot /* likewise: parallel to stage[] */)
+    Progress *prog /* KG_F_PROGRESS (COUNTERS kernels), else null */, uint32_t *__restrict__ stage_slot /* likewise: parallel to stage[] */,
+    const uint32_t *__restrict__ hbits /* one bit per slot (build_hbits_kernel) or null; not read by COUNTERS kernels */, uint64_t tail_start)
 {
     constexpr int ROWS = AA ? 1 : 6;
     constexpr int NG = ROWS / RPG;
@@ -805,6 +806,21 @@ __global__ __launch_bounds__(kWave *kWavesPerWG) void scan_kernel(
                 val[q] = (uint64_t)hi * 160000ull + lo;
             }
 
+            // Tables whose bit-per-slot digest stays in the L2 (a 20 M-slot table: 2.5 MB of bits against 20 MB of tags, which come
+            // from the memory-side cache at a quarter of the L2's gather rate): a query whose home slot is the home of no
+            // findable key (61 % at load 0.49) is a miss for certain and never asks for its tags; its walk would have ended
+            // with the stream iff the home slot lies in the occupied run at the table's end (as in bucket_index_kernel).
+            if (!COUNTERS && hbits) {
+                uint32_t w[RPG];
+#pragma unroll
+                for (int q = 0; q < RPG; q++) w[q] = valid[q] && home[q] < limit ? hbits[home[q] >> 5] : ~0u;
+#pragma unroll
+                for (int q = 0; q < RPG; q++)
+                    if (valid[q] && home[q] < limit && !((w[q] >> ((uint32_t)home[q] & 31u)) & 1u)) {
+                        valid[q] = false;
+                        if (home[q] >= tail_start) ran_off = true;
+                    }
+            }
             Payload ent[RPG];
             uint32_t fslot[RPG];
 #pragma unroll
@@ -1173,6 +1189,29 @@ __global__ void build_bidx_kernel(const uint8_t *entries, const uint8_t *tags, u
             if (j < limit && j - h >= kHomeWalkMax) complete = false;
         }
         idx[h] = (uint8_t)bidx_encode(mask, complete);
+    }
+}
+
+// One BIT per slot of the byte home index: set iff the byte is not 0 (some findable key has its home there, or the run was
+// not walked to its end): the direct kernel's first question on tables whose bits fit the L2.  n_words words; bytes behind
+// n_idx count as 0.
+__global__ void build_hbits_kernel(const uint8_t *__restrict__ idx, uint64_t n_idx, uint32_t *__restrict__ bits, uint64_t n_words)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        uint32_t out = 0;
+        const uint64_t s0 = w * 32;
+        if (s0 + 32 <= n_idx) {                                   // (idx is a hipMalloc block: 16-byte aligned at every s0)
+            const uint4 a = *reinterpret_cast<const uint4 *>(idx + s0), b = *reinterpret_cast<const uint4 *>(idx + s0 + 16);
+            const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) out |= (((v[k] >> (8 * j)) & 0xFFu) != 0u ? 1u : 0u) << (4 * k + j);
+        } else {
+            for (uint32_t j = 0; j < 32 && s0 + j < n_idx; j++) out |= (idx[s0 + j] != 0 ? 1u : 0u) << j;
+        }
+        bits[w] = out;
     }
 }
 

@@ -171,6 +171,8 @@ struct PinCache {
 
 }  // namespace
 
+constexpr uint64_t kHbitsMaxSlots = 1ull << 26;     // tables up to this many slots get the bit-per-slot digest (8 MB of bits)
+
 struct kg_table {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -184,6 +186,7 @@ struct kg_table {
     uint8_t *d_tags = nullptr;
     uint8_t *d_bidx = nullptr;          // byte home index (kg_device.hpp, build_bidx_kernel): 1 byte per slot, limit + 64 bytes
     bool bidx_exact = false;            // every quotient < 19: its classes are quotients
+    uint32_t *d_hbits = nullptr;        // one bit per slot: the byte above is not 0 (tables of at most kHbitsMaxSlots slots: the direct kernel's prefilter)
     uint64_t tail_start = 0;            // first slot of the occupied run that ends at the end of the record stream
     int64_t num_sigs = 0, entry_size = 0, version = 0;
     uint64_t limit = 0;          // complete 24-byte records present
@@ -290,6 +293,16 @@ int table_finish(kg_table *t)
         hipLaunchKernelGGL(kg::build_bidx_kernel, dim3((uint32_t)std::min<uint64_t>(wantb, 256ull * 32)), dim3(256), 0, t->stream,
                            t->d_entries, t->d_tags, t->limit, n_bidx, (uint64_t)t->num_sigs, t->magic, t->d_bidx);
         HIP_TRY(hipGetLastError());
+        // ... and, for tables whose bits stay in an XCD's L2 or close to it, its one-bit-per-slot digest: the direct kernel asks it
+        // first (scan_kernel).  2^26 slots = 8 MB of bits: the gather rate there is still twice that of a tag array eight times
+        // the size (profiles/r01_gather_ceiling_small_tables.jsonl).
+        if (n_bidx <= kHbitsMaxSlots) {
+            const uint64_t n_words = (n_bidx + 31) / 32;
+            HIP_TRY(hipMalloc((void **)&t->d_hbits, n_words * 4));
+            hipLaunchKernelGGL(kg::build_hbits_kernel, dim3((uint32_t)std::min<uint64_t>((n_words + 255) / 256, 256ull * 32)), dim3(256), 0, t->stream,
+                               t->d_bidx, n_bidx, t->d_hbits, n_words);
+            HIP_TRY(hipGetLastError());
+        }
     }
     unsigned long long occ[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(occ, d_occ, 16, hipMemcpyDeviceToHost, t->stream));
@@ -564,6 +577,7 @@ void kg_table_close(kg_table *t)
     if (t->own_entries && t->d_entries) (void)hipFree(t->d_entries);
     if (t->d_tags) (void)hipFree(t->d_tags);
     if (t->d_bidx) (void)hipFree(t->d_bidx);
+    if (t->d_hbits) (void)hipFree(t->d_hbits);
     t->cache.release_all();
     t->pins.release_all();
     if (t->h_pin) (void)hipHostFree(t->h_pin);
@@ -1276,9 +1290,15 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
     // persistent grid: enough workgroups to fill 256 CUs, few enough that per-wave staging chunks stay small
     const uint32_t scan_grid = env_u32("KG_SCAN_GRID", 256u * 8u);
     const uint32_t stage_chunk = env_u32("KG_STAGE_CHUNK", 256u);
-    uint32_t rpg = AA ? 1u : env_u32("KG_SCAN_RPG", 3u);      // rows probed together per lane
+    // the table's bit-per-slot digest as the direct kernel's first question (tables of <= kHbitsMaxSlots slots; not for scans
+    // that count the slots they inspect): config 5's scan 2.28 -> 1.80 ms (r04 c34)
+    // KG_DIRECT_FILTER: 0 never, 1 (default) when the tags no longer fit an XCD's 4 MB L2 (below that the bit is one more
+    // dependent load in front of an L2 hit), 2 whenever the table has the digest (tests)
+    const uint32_t filter_mode = env_u32("KG_DIRECT_FILTER", 1u);
+    const uint32_t *d_hbits_scan = (counters || filter_mode == 0 || (filter_mode == 1 && t->limit <= (4ull << 20))) ? nullptr : t->d_hbits;
+    // rows probed together per lane: three; six behind the digest, where two probes out of three end at the bit (1.80 -> 1.75 ms)
+    uint32_t rpg = AA ? 1u : env_u32("KG_SCAN_RPG", d_hbits_scan ? 6u : 3u);
     if (rpg != 1 && rpg != 2 && rpg != 3 && rpg != 6) rpg = 3;
-    (void)0;
     uint64_t stage_cap = (uint64_t)((double)windows * t->stage_ratio) + 4096 +
                          (uint64_t)scan_grid * kg::kWavesPerWG * stage_chunk;
     if (stage_cap > 0xFFFFFF00ull) stage_cap = 0xFFFFFF00ull;
@@ -1297,7 +1317,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             uint64_t wgs = (nblocks + kg::kWavesPerWG - 1) / kg::kWavesPerWG;
             uint32_t grid = (uint32_t)(wgs < scan_grid ? wgs : scan_grid);      // persistent waves stride over the blocks
 #define KG_SCAN_ARGS t->d_entries, t->d_tags, t->limit, (uint64_t)t->num_sigs, t->magic, t->m35, d_seq, d_blocks, (uint32_t)nblocks, \
-                     d_counts, d_bsb, d_stage, d_cursor, stage_cap, stage_chunk, d_ctr, d_prog, d_stage_slot
+                     d_counts, d_bsb, d_stage, d_cursor, stage_cap, stage_chunk, d_ctr, d_prog, d_stage_slot, \
+                     d_hbits_scan, t->tail_start
 #define KG_SCAN_LAUNCH(C, R) hipLaunchKernelGGL((kg::scan_kernel<AA, C, R>), dim3(grid), dim3(kg::kWave * kg::kWavesPerWG), 0, \
                                                 t->stream, KG_SCAN_ARGS)
             if (AA) {

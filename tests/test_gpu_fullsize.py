@@ -389,6 +389,7 @@ def test_config1_plumbing_at_its_stated_size(hp, oracle, strategy, monkeypatch):
     sb = seq.numpy().tobytes()
     monkeypatch.setenv("KG_PARTITION", "0" if strategy == "direct" else "1")
     monkeypatch.setenv("KG_BIDX", "0" if strategy == "partitioned_tags" else "1")
+    monkeypatch.setenv("KG_DIRECT_FILTER", "2")      # direct, no counters: behind the bit-per-slot digest (default: tables > 4 M slots only)
     # the same keys with ONE function per protein for the signatures drawn from it: the reference's defaults then CALL
     seq_c, off_c, rec_c, placed_c = synth.plumbing_config(coherent=True)
     assert placed_c == placed and np.array_equal(off_c, off)

@@ -15,7 +15,7 @@ from helpers import assert_same_records
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_SLACK", "KG_TEST_TINY_LISTS", "KG_PART_OVF_GROUPS",
-         "KG_BIDX", "KG_INDEX_R")
+         "KG_BIDX", "KG_INDEX_R", "KG_DIRECT_FILTER")
 
 
 @pytest.mark.parametrize("seed", [21, 22])
@@ -30,6 +30,7 @@ def test_both_strategies_against_the_oracle(oracle, monkeypatch, seed):
                 for k in KNOBS:
                     monkeypatch.delenv(k, raising=False)
                 monkeypatch.setenv("KG_PARTITION", "0" if mode == "0" else "1")
+                monkeypatch.setenv("KG_DIRECT_FILTER", "2" if w["it"] % 2 == 0 else "1")      # (2: the digest whatever the table's size)
                 if mode != "0":
                     for k, v in w["env"].items():
                         monkeypatch.setenv(k, v)
@@ -40,6 +41,10 @@ def test_both_strategies_against_the_oracle(oracle, monkeypatch, seed):
                     assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s %s" % (seed, w["it"], mode, w["env"], w["env2"] if mode == "2" else ""))
                     assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
                     n_part += r.stats["partitioned"]
+                if mode == "0":
+                    # without KG_F_COUNTERS the direct kernel asks the table's bit-per-slot digest before the tags
+                    with tab.scan(w["raw"], w["off"], hotpath.Params(**p)) as r:
+                        assert_same_records(r, ora, "fuzz seed %d it %d direct, no counters" % (seed, w["it"]))
                 if mode != "0":
                     # without KG_F_COUNTERS: mode "1" probes the table's byte home index (bucket_index_kernel), mode "2" the tags
                     with tab.scan(w["raw"], w["off"], hotpath.Params(**p)) as r:

@@ -22,6 +22,7 @@ K1 = {"AAAAAAAA": 0, "ACDEFGHI": 70914127, "MKLVTGAS": 13343650015, "YYYYYYYY": 
 
 def _strategy(monkeypatch, strategy):
     monkeypatch.setenv("KG_PARTITION", "0" if strategy == "direct" else "1")
+    monkeypatch.setenv("KG_DIRECT_FILTER", "2")          # the direct kernel behind the bit-per-slot digest, whatever the table's size
     monkeypatch.setenv("KG_BIDX", "0" if strategy == "partitioned_tags" else "1")
 
 

@@ -19,20 +19,24 @@ def strategy(request, monkeypatch):
     KG_F_COUNTERS, the tags by scans with them; and the same with the index switched off (KG_BIDX=0: tags for every scan).
     Most workloads here scan with counters (they compare them with the oracle's), which the index path does not serve: under
     "partitioned" every such scan is therefore REPEATED without counters -- the index path -- and its records, event bytes and
-    flags must be the ones of the scan the test goes on to compare with the oracle."""
+    flags must be the ones of the scan the test goes on to compare with the oracle.  Likewise under "direct": without counters
+    the direct kernel first asks the table's bit-per-slot digest (scan_kernel, hbits)."""
     monkeypatch.setenv("KG_PARTITION", "0" if request.param == "direct" else "1")
+    monkeypatch.setenv("KG_DIRECT_FILTER", "2")          # (by default only tables of more than 4 M slots are asked through the digest)
     if request.param == "partitioned_tags":
         monkeypatch.setenv("KG_BIDX", "0")
-    if request.param == "partitioned":
+    if request.param in ("partitioned", "direct"):
         import dataclasses
         from kmergutsjava_amd import hotpath
         plain = hotpath.SignatureTable.scan
+        direct = request.param == "direct"      # the direct kernel without counters asks the table's bit-per-slot digest first
 
         def scan_and_cross_check(self, seq, offsets, params=None, device_ptr=None):
             r = plain(self, seq, offsets, params, device_ptr)
-            if params is not None and params.counters and r.stats["partitioned"] == 1:
+            if params is not None and params.counters and r.stats["partitioned"] == (0 if direct else 1):
                 with plain(self, seq, offsets, dataclasses.replace(params, counters=False), device_ptr) as ri:
-                    assert ri.stats["part_levels"] == 4, ri.stats
+                    assert direct or ri.stats["part_levels"] == 4, ri.stats
+                    assert ri.stats["partitioned"] == r.stats["partitioned"]
                     for kind in ("hits", "calls", "otu", "hit_events", "container_tail_events", "container_hit_start", "container_call_start"):
                         assert getattr(ri, kind)().tobytes() == getattr(r, kind)().tobytes(), "index path vs tag path: %s differ" % kind
                     for k in ("n_hits", "n_calls", "lookup_ran_off", "fallback"):
