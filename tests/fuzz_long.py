@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long differential fuzz against the CPU oracle (test infrastructure; not collected by pytest):
     python tests/fuzz_long.py [n_workloads=400] [first_seed=1000]
-Every workload of tests/fuzz_workloads.py through the scan strategies (direct; partitioned on the byte home index and on the tags, with and without counters), records, event bytes, counters and flags compared
+Every workload of tests/fuzz_workloads.py through the scan strategies (direct, behind the bit-per-slot digest and not; partitioned on the byte home index and on the tags; each with and without counters), records, event bytes, counters and flags compared
 with the oracle.  Prints one JSON summary line; exit code 1 on the first difference."""
 import json
 import os
@@ -15,7 +15,7 @@ from fuzz_workloads import workloads          # noqa: E402
 from helpers import assert_same_records       # noqa: E402
 
 KNOBS = ("KG_PARTITION", "KG_PART_CHUNKS", "KG_PART_MIN_CHUNK_BLOCKS", "KG_PART_SLACK", "KG_TEST_TINY_LISTS", "KG_PART_OVF_GROUPS",
-         "KG_BIDX", "KG_INDEX_R")
+         "KG_BIDX", "KG_INDEX_R", "KG_DIRECT_FILTER")
 
 
 def main():
@@ -34,6 +34,7 @@ def main():
                     for k in KNOBS:
                         os.environ.pop(k, None)
                     os.environ["KG_PARTITION"] = "0" if mode == "0" else "1"
+                    os.environ["KG_DIRECT_FILTER"] = "2" if w["it"] % 2 == 0 else "1"      # (2: the bit-per-slot digest whatever the table's size)
                     if mode != "0":
                         os.environ.update(w["env"])
                     if mode == "2":
@@ -42,7 +43,7 @@ def main():
                         assert_same_records(r, ora, "fuzz seed %d it %d mode %s %s %s" % (seed, w["it"], mode, w["env"], w["env2"] if mode == "2" else ""))
                         assert r.stats["windows_valid"] == ora["windows_valid"] and r.stats["slots_inspected"] == ora["slots_inspected"]
                         n_part += r.stats["partitioned"]
-                    if mode != "0":                        # without KG_F_COUNTERS: the byte-index kernel ("1") / the plain tag kernel ("2")
+                    if True:                               # without KG_F_COUNTERS: the direct kernel behind the digest ("0") / the byte-index kernel ("1") / the plain tag kernel ("2")
                         with tab.scan(w["raw"], w["off"], hotpath.Params(**p)) as r:
                             assert_same_records(r, ora, "fuzz seed %d it %d mode %s no counters %s" % (seed, w["it"], mode, w["env"]))
             done += 1
@@ -50,7 +51,7 @@ def main():
             hits += len(ora["hits"])
             if done >= n:
                 break
-    print(json.dumps({"workloads": done, "scans": 5 * done, "ran_partitioned": n_part, "oracle_hits": hits, "oracle_calls": calls,
+    print(json.dumps({"workloads": done, "scans": 6 * done, "ran_partitioned": n_part, "oracle_hits": hits, "oracle_calls": calls,
                       "all_identical": True}))
 
 
