@@ -218,6 +218,13 @@ def test_config5_high_density_full_size(hp, oracle, dna, monkeypatch):
             with tab.scan(None, off, hp.Params(aa=not dna), device_ptr=seq.data_ptr()) as rb:
                 assert rb.stats["partitioned"] != ra.stats["partitioned"] and rb.stats["fallback"] == 0, rb.stats
                 _same_on_device(ra, rb, "config 5 dna=%s, the two strategies" % dna)
+            # ra ran the direct kernel behind the table's bit-per-slot digest (20 M slots: the default there); the same without
+            monkeypatch.setenv("KG_PARTITION", "0")
+            monkeypatch.setenv("KG_DIRECT_FILTER", "0")
+            with tab.scan(None, off, hp.Params(aa=not dna), device_ptr=seq.data_ptr()) as rc:
+                assert rc.stats["partitioned"] == 0
+                _same_on_device(ra, rc, "config 5 dna=%s, direct with and without the digest" % dna)
+                assert rc.stats["lookup_ran_off"] == ra.stats["lookup_ran_off"]
 
 
 def test_table_with_more_than_2_31_slots(hp, oracle):
