@@ -687,19 +687,17 @@ __global__ __launch_bounds__(256) void otu_wave_kernel(const int32_t *__restrict
             const int32_t rlen = above ? __builtin_ctzll(above) + 1 : nv - lane;
             // With one wave per SIMD every instruction of a step is on the clock (config 5: 3 300 steps per sequence, nothing
             // else to run): ballots of ONE compare each, masked with scalar masks (a ballot of "lane < n && ..." costs two more
-            // VALU instructions); the lanes behind n hold nothing that is ever read, so the count is raised wherever the
-            // otuIndex matches; and the common outcome of the bubble -- the entry in front has more, nothing moves -- is one
+            // VALU instructions); and the common outcome of the bubble -- the entry in front has more, nothing moves -- is one
             // bit test.
             while (heads) {
                 const int k = __builtin_ctzll(heads);
                 heads &= heads - 1;
                 const int32_t ok = rl(o, k), r = rl(rlen, k);
-                const bool same = oi == ok;
-                const uint64_t at = __ballot(same) & nmask;                 // KGJ:416-417 linear search (entries are distinct)
-                int j;
+                const uint64_t at = __ballot(oi == ok) & nmask;             // KGJ:416-417 linear search: the FIRST entry that
+                int j;                                                      // carries it (a caller's buffer may hold it twice)
                 if (at) {
                     j = __builtin_ctzll(at);
-                    cnt += same ? r : 0;
+                    cnt += lane == j ? r : 0;
                 } else {                                                    // KGJ:418-427: append, or overwrite the last entry
                     if (n == KG_OI_BUFSZ) j = KG_OI_BUFSZ - 1; else { j = n++; nmask = nmask * 2u + 1u; }
                     if (lane == j) { oi = ok; cnt = r; }

@@ -43,6 +43,8 @@ def test_gather_hits_and_process_aa_seq(debug):
         k = K()
         k.aa, k.orderConstraint, k.minHits, k.minWeightedHits, k.maxGap, k.debug = True, oc, mh, mw, gap, debug
         start = [(3, 2), (2, 5)] if trial % 4 == 0 else []                   # (count, oI): a buffer that is not empty
+        if trial % 4 == 2:       # ... and one no run of the reference could have left behind: an otuIndex twice, counts out of order
+            start = [(1, 2), (4, 5), (2, 2), (6, 3)]
         m_hits = [M.Hit(*t) for t in tup]
         m_oi = [[c, o] for c, o in start]
         m_pw = io.StringIO()
