@@ -16,7 +16,9 @@ tabs = [hotpath.SignatureTable.from_device_ptr(rec.data_ptr(), num_sigs, 0, keep
 all_lens = synth.contig_mix_lengths(1_000_000_000, 301); all_off = synth.offsets_of(all_lens)
 
 
-def run(tab, seq, off, n, out):
+def run(tab, seq, off, n, out, delay=0.0):
+    if delay:
+        time.sleep(delay)                              # SW_STAGGER_MS: the second thread starts in the middle of the first one's scan
     for _ in range(n):
         with tab.scan(None, off, hotpath.Params(), device_ptr=seq.data_ptr()) as r:
             r.calls(); r.otu(); out.append(r.stats["n_hits"])
@@ -38,7 +40,8 @@ for case in cases:
     torch.cuda.synchronize()
     serial = (time.perf_counter() - t0) / n_scans * 1e3
     t0 = time.perf_counter(); h2 = [[], []]
-    th = [threading.Thread(target=run, args=(tabs[k], seq, off, n_scans // 2, h2[k])) for k in range(2)]
+    stagger = float(os.environ.get("SW_STAGGER_MS", "0")) * 1e-3
+    th = [threading.Thread(target=run, args=(tabs[k], seq, off, n_scans // 2, h2[k], stagger * k)) for k in range(2)]
     for x in th: x.start()
     for x in th: x.join()
     torch.cuda.synchronize()
