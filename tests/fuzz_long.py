@@ -47,6 +47,8 @@ def main():
                         with tab.scan(w["raw"], w["off"], hotpath.Params(**p)) as r:
                             assert_same_records(r, ora, "fuzz seed %d it %d mode %s no counters %s" % (seed, w["it"], mode, w["env"]))
             done += 1
+            if done % 100 == 0:                                        # (a run that writes nothing for minutes is taken to be hung)
+                print("[fuzz_long] %d workloads identical so far" % done, file=sys.stderr, flush=True)
             calls += len(ora["calls"])
             hits += len(ora["hits"])
             if done >= n:
