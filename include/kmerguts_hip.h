@@ -21,7 +21,7 @@
  *   KG_PARTITION (0 direct / 1 partitioned whenever possible / 2 auto), KG_BIDX (0: probe the tags, not the byte home index),
  *   KG_PART_SHIFT, KG_PART_CHUNKS, KG_PART_MIN_CHUNK_BLOCKS, KG_PART_WGS, KG_PART_SLACK, KG_PART_OVF_GROUPS, KG_PART_TAPER,
  *   KG_PROBE_GRID, KG_INDEX_GRID, KG_INDEX_R, KG_PROBE_GRAB, KG_VERIFY_GRID, KG_LOWC_GRID, KG_OVF_GRID,
- *   KG_ORDER_GRID, KG_ORDER_STREAMS, KG_PLACE_STAGED, KG_SCAN_GRID, KG_SCAN_RPG, KG_DIRECT_FILTER, KG_STAGE_CHUNK, KG_AGG_PIECES, KG_AGG_PAIRS, KG_AGG_BLOCK_SHIFT:
+ *   KG_ORDER_GRID, KG_ORDER_STREAMS, KG_PLACE_STAGED, KG_SCAN_GRID, KG_SCAN_RPG, KG_DIRECT_FILTER, KG_SCATTER_PRIO, KG_INDEX_PRIO, KG_VERIFY_PRIO, KG_STAGE_CHUNK, KG_AGG_PIECES, KG_AGG_PAIRS, KG_AGG_BLOCK_SHIFT:
  *   geometry of the
  *   scan strategies (kmerguts_hip.hip, scan_impl); results never depend on them.  KG_DEBUG: one stderr line per attempt.
  *   TEST HOOKS (used by tests/ only; inert unless the process set KG_ENABLE_TEST_HOOKS=1 before its FIRST kg_scan* -- that

@@ -60,6 +60,17 @@ struct TableView {
     uint32_t m35;        // floor(2^35 / num_sigs) when 64 <= num_sigs < 2^31 (split_fast applies), else 0
 };
 
+// The wave's issue priority among the waves of its SIMD (0..3; the instruction takes an immediate).  The kernels that share the CUs
+// in the partitioned pipeline set it per phase: a wave that issues a few instructions between long waits (LDS round trips of the
+// scatter pass's insert phase, L2 round trips of the index pass) should not queue behind other waves' VALU streams.
+__device__ __forceinline__ void set_wave_prio(uint32_t p)
+{
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_sync()
 {

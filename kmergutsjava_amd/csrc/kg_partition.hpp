@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
     uint64_t limit, uint32_t num_sigs /* 64 <= num_sigs < 2^31 */, uint32_t m35, uint32_t shift, uint32_t n_buckets, uint32_t cap,
     uint64_t *__restrict__ ent, uint32_t *__restrict__ fill, uint32_t *ovf_cursor, uint32_t ovf_cap, uint32_t *__restrict__ ovf_bucket,
     uint64_t *__restrict__ ovf_ent, uint32_t *lowc_cursor /* [0] count */, uint32_t *__restrict__ lowc_blocks, unsigned long long *ctr,
-    Progress *prog /* KG_F_PROGRESS, else null */)
+    Progress *prog /* KG_F_PROGRESS, else null */, uint32_t insert_prio /* wave priority of the insert phase (0..3) */)
 {
     constexpr int ROWS = AA ? 1 : 6;
     typedef typename WaveLds<AA>::type Enc;
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
         // fallback to the direct strategy (sticky word ovf_cursor[2], kg_stats.fallback == 2) instead of a hang or a
         // wrong result.
         uint32_t done = 0, spins = 0;
+        if (insert_prio) set_wave_prio(insert_prio);                   // (uniform) few instructions between long LDS waits
         for (;;) {
             uint32_t at[RG];
 #pragma unroll
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(kWave *kScatterWaves) KG_SCATTER_REGS void part_sca
                 break;
             }
         }
+        if (insert_prio) set_wave_prio(0);
         }   // row group
     }
     __syncthreads();
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
     uint32_t shift, uint32_t grab /* entry slots (of every region) per hand-out, multiple of 256 * N / R */,
     uint32_t *next_region /* ticket counter of group x at [32 * x], zeroed */,
     CandRec *__restrict__ cand, uint32_t *__restrict__ cand_used, unsigned long long *cand_cursor, uint64_t cand_cap,
-    unsigned long long *ctr)
+    unsigned long long *ctr, uint32_t prio /* wave priority (0..3) */)
 {
     static_assert(N % R == 0, "R must divide N");
     constexpr int PER = N / R;                          // entries per lane, region and iteration
@@ -829,6 +831,7 @@ __global__ __launch_bounds__(256) KG_TAG_REGS void bucket_index_kernel(
     UListState u;
     u.base = 0; u.used = kUChunk; u.have = false;      // "full": the first append takes a chunk
     s_lut[threadIdx.x] = bidx_decode(threadIdx.x);      // (256 threads; the loop's first barrier publishes it)
+    if (prio) set_wave_prio(prio);                      // a few instructions between L2 round trips: ahead of the scatter waves' VALU streams
 
     const uint32_t kGrab = grab;
     const uint32_t grabs_per_region = (cap + kGrab - 1) / kGrab;
@@ -937,11 +940,13 @@ __global__ __launch_bounds__(256) void verify_kernel(
     const uint8_t *__restrict__ entries, const uint8_t *__restrict__ tags, uint64_t limit, uint64_t num_sigs, uint64_t magic,
     const CandRec *__restrict__ cand, const uint32_t *__restrict__ cand_used, const unsigned long long *cand_cursor,
     uint64_t cand_cap, kg_hit *__restrict__ ulist, uint32_t *__restrict__ chunk_used, unsigned long long *cursor,
-    uint64_t ulist_cap, unsigned long long *ctr, Progress *prog /* KG_F_PROGRESS (COUNTERS kernels), else null */)
+    uint64_t ulist_cap, unsigned long long *ctr, Progress *prog /* KG_F_PROGRESS (COUNTERS kernels), else null */,
+    uint32_t prio /* wave priority (0..3) */)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4;
+    if (prio) set_wave_prio(prio);
     TableView tab;
     tab.entries = entries; tab.tags = tags; tab.limit = limit; tab.num_sigs = num_sigs; tab.magic = magic; tab.m35 = 0;
     const unsigned long long cur = *cand_cursor;

@@ -1021,6 +1021,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         const uint32_t index_grid = env_u32("KG_INDEX_GRID", 256u * 4u) & ~7u;
         // ... and the regions it takes per hand-out: regions expected to hold fewer than ~640 / ~320 entries (about 0.7 of the
         // mean the capacity was computed from is valid DNA) are handed out two / four at a time (bucket_index_kernel)
+        // wave priorities (s_setprio) of the two passes that share the CUs: kg_device.hpp, set_wave_prio
+        const uint32_t scatter_prio = std::min(3u, env_u32("KG_SCATTER_PRIO", 1u)), index_prio = std::min(3u, env_u32("KG_INDEX_PRIO", 2u)),
+                       verify_prio = std::min(3u, env_u32("KG_VERIFY_PRIO", n_chunks_p == 1 ? 2u : 0u));
         uint32_t index_r = env_u32("KG_INDEX_R", 0u);
         if (index_r == 0) index_r = mean * 0.7 >= 640.0 ? 1u : mean * 0.7 >= 320.0 ? 2u : 4u;
         if (index_r != 1 && index_r != 2) index_r = 4;
@@ -1109,7 +1112,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 if (!seq_uploaded && (rc = upload(offsets[cseq[c]], offsets[cseq[c + 1]]))) return rc;
                 hipLaunchKernelGGL((kg::part_scatter_kernel<AA>), dim3(n_wg), dim3(kg::kWave * kg::kScatterWaves), lds, t->stream, d_seq,
                                    d_blocks, lo, nb, t->limit, (uint32_t)t->num_sigs, t->m35, part_shift, part_buckets,
-                                   cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, ovfc_c + 1, d_lowc + lo, d_ctr, d_prog);
+                                   cap, ent_c, fill_c, ovfc_c, ovf_cap, ovf_bucket_c, ovf_ent_c, ovfc_c + 1, d_lowc + lo, d_ctr, d_prog, scatter_prio);
                 hipStream_t s2 = t->stream2, s3 = t->stream3;
                 HIP_TRY(hipEventRecord(t->pev[2 * c], t->stream));
                 HIP_TRY(hipStreamWaitEvent(t->stream2, t->pev[2 * c], 0));
@@ -1126,7 +1129,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
 #define KG_ULIST_ARGS ulist_c, cused_c, ucur_c, ucap, d_ctr, d_prog
                 if (use_bidx) {
 #define KG_INDEX_ARGS t->d_bidx, (uint32_t)std::min<uint64_t>(t->tail_start, 0xFFFFFFFFull), ent_c, fill_c, n_wg, cap, \
-                      part_buckets, part_shift, probe_grab, next_c, cand_c, candused_c, ccur_c, ccap, d_ctr
+                      part_buckets, part_shift, probe_grab, next_c, cand_c, candused_c, ccur_c, ccap, d_ctr, index_prio
 #define KG_INDEX_LAUNCH(R, X) hipLaunchKernelGGL((kg::bucket_index_kernel<kg::kIndexN, R, X>), dim3(index_grid), dim3(256), 0, s2, KG_INDEX_ARGS)
                     // regions per hand-out by their expected fill (an iteration covers 256 * N / R entry slots of each); the
                     // kernel for tables whose classes are their quotients has no q % 19
@@ -1141,12 +1144,12 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                 HIP_TRY(hipStreamWaitEvent(s3, t->pev[2 * c + 1], 0));
                 if (counters) {
                     hipLaunchKernelGGL((kg::verify_kernel<AA, true>), dim3(verify_grid), dim3(256), 0, s3, KG_PROBE_ARGS, cand_c,
-                                       candused_c, ccur_c, ccap, KG_ULIST_ARGS);
+                                       candused_c, ccur_c, ccap, KG_ULIST_ARGS, verify_prio);
                     hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, true>), dim3(ovf_grid), dim3(256), 0, s3, KG_PROBE_ARGS,
                                        ovf_bucket_c, ovf_ent_c, ovfc_c, ovf_cap, part_shift, KG_ULIST_ARGS);
                 } else {
                     hipLaunchKernelGGL((kg::verify_kernel<AA, false>), dim3(verify_grid), dim3(256), 0, s3, KG_PROBE_ARGS, cand_c,
-                                       candused_c, ccur_c, ccap, KG_ULIST_ARGS);
+                                       candused_c, ccur_c, ccap, KG_ULIST_ARGS, verify_prio);
                     hipLaunchKernelGGL((kg::overflow_probe_kernel<AA, false>), dim3(ovf_grid), dim3(256), 0, s3, KG_PROBE_ARGS,
                                        ovf_bucket_c, ovf_ent_c, ovfc_c, ovf_cap, part_shift, KG_ULIST_ARGS);
                 }
