@@ -918,10 +918,18 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         uint32_t want = env_u32("KG_PART_CHUNKS", 4u);
         if (want < 1) want = 1;
         if (want > kMaxChunks) want = kMaxChunks;
-        // at least ~115 Mbp per chunk (tests lower it): a pass has costs that do not shrink with the chunk -- a 125 Mbp shard is
-        // slower in two chunks (3.00 ms against 2.95, r04 c07), 250 Mbp faster (4.99 against 5.25)
-        const uint64_t min_chunk = std::max(1u, env_u32("KG_PART_MIN_CHUNK_BLOCKS", 600000u));
-        while (want > 1 && nblocks / want < min_chunk) want--;
+        // How many: a pass has costs that do not shrink with the chunk, so small batches take few.  Measured with the wave
+        // priorities in place (r04 c59; ms per scan in 1 / 2 / 3 / 4 chunks): 100 Mbp 2.50 / 2.46 / 2.72 / -, 125 Mbp 2.94 / 2.87 /
+        // 3.17 / -, 250 Mbp 5.15 / 4.83 / 5.17 / -, 500 Mbp - / - / 8.63 / 9.0, 1 Gbp - / - / 16.0 / 15.1 (five: 15.45):
+        // round(sqrt(blocks / 325 000)) but at least two, one below 450 000 blocks (~85 Mbp).  KG_PART_MIN_CHUNK_BLOCKS (tests) replaces the
+        // rule by "as many as KG_PART_CHUNKS allows with at least that many blocks each".
+        if (getenv("KG_PART_MIN_CHUNK_BLOCKS")) {
+            const uint64_t min_chunk = std::max(1u, env_u32("KG_PART_MIN_CHUNK_BLOCKS", 600000u));
+            while (want > 1 && nblocks / want < min_chunk) want--;
+        } else {
+            const uint32_t by_size = nblocks < 450000 ? 1u : std::max(2u, (uint32_t)std::lround(std::sqrt((double)nblocks / 325000.0)));
+            want = std::min(want, std::max(1u, by_size));
+        }
         std::vector<uint64_t> clo;                                                    // chunk c = blocks [clo[c], clo[c+1])
         std::vector<int64_t> cseq;                                                    //         = sequences [cseq[c], cseq[c+1])
         clo.push_back(0); cseq.push_back(0);

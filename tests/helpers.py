@@ -78,18 +78,23 @@ def plant(seq_bytes: bytes, off, keys, every=40, dna=True, start=10):
     return bytes(s)
 
 
-def chunk_seq_ranges(off, want=4, dna=True, min_chunk_blocks=600000):
+def chunk_seq_ranges(off, want=4, dna=True, min_chunk_blocks=None):
     """The sequence ranges [a, b) of the chunks the partitioned scan cuts a batch into (kmerguts_hip.hip, scan_impl:
-    chunk c starts at the first sequence whose first window block is >= nblocks * c / want; fewer chunks while a
-    chunk would hold fewer than min_chunk_blocks blocks).  A DNA block is 192 forward positions, a protein block
-    64 windows."""
+    chunk c starts at the first sequence whose first window block is >= nblocks * c / want; the number of chunks by
+    the batch's size -- round(sqrt(blocks / 325 000)), at least two, one below 450 000 blocks -- or, with
+    KG_PART_MIN_CHUNK_BLOCKS = min_chunk_blocks, fewer chunks while a chunk would hold fewer blocks than that).
+    A DNA block is 192 forward positions, a protein block 64 windows."""
     L = np.asarray(off[1:] - off[:-1], dtype=np.int64)
     nb = (np.maximum(L - 23, 0) + 191) // 192 if dna else (np.maximum(L - 8, 0) + 63) // 64
     ibase = np.zeros(len(L) + 1, dtype=np.int64)
     np.cumsum(nb, out=ibase[1:])
     nblocks = int(ibase[-1])
-    while want > 1 and nblocks // want < min_chunk_blocks:
-        want -= 1
+    if min_chunk_blocks is not None:
+        while want > 1 and nblocks // want < min_chunk_blocks:
+            want -= 1
+    else:
+        by_size = 1 if nblocks < 450000 else max(2, int(np.floor(np.sqrt(nblocks / 325000.0) + 0.5)))
+        want = min(want, max(1, by_size))
     cuts, clo = [0], [0]
     for c in range(1, want):
         k = int(np.searchsorted(ibase, nblocks * c // want, side="left"))
