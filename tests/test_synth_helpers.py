@@ -38,9 +38,14 @@ def test_spread_sample_and_chunk_ranges():
     for a, b in ranges:
         got = idx[(idx >= a) & (idx < b)]
         assert len(got) >= 3 and int(lens[got].sum()) <= 2_500_000 + int(lens[got].max())
-    # small batches: fewer chunks (the library never cuts below 2^20 blocks per chunk), the sample still spreads
+    # small batches: fewer chunks (two for 125 Mbp, one below ~85 Mbp: the library's size rule), the sample still spreads
     lens2 = synth.contig_mix_lengths(125_000_000, 301)
     off2 = synth.offsets_of(lens2)
-    assert chunk_seq_ranges(off2, 4) == [(0, len(lens2))]
+    r2 = chunk_seq_ranges(off2, 4)
+    assert len(r2) == 2 and r2[0][0] == 0 and r2[0][1] == r2[1][0] and r2[1][1] == len(lens2)
+    lens3 = synth.contig_mix_lengths(60_000_000, 301)
+    assert chunk_seq_ranges(synth.offsets_of(lens3), 4) == [(0, len(lens3))]
+    assert len(chunk_seq_ranges(synth.offsets_of(synth.contig_mix_lengths(500_000_000, 301)), 4)) == 3
+    assert chunk_seq_ranges(off2, 4, min_chunk_blocks=600000) == [(0, len(lens2))]      # KG_PART_MIN_CHUNK_BLOCKS: the explicit rule
     idx2 = synth.spread_sample(off2, groups=4, per_group=5)
     assert len(idx2) >= 4 and idx2[0] > 0 and idx2[-1] < len(lens2)
