@@ -1180,6 +1180,7 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             // of chunks 0-2 then all crawl beside the last tag passes, single scans 20.1-20.25 ms against 20.4, but twenty
             // scans back to back (bench.py) 21.45 against 21.23 ms per step (profiles/r03_experiments.md).
             const uint32_t n_os = n_chunks_p < 2 ? 0u : std::min(env_u32("KG_ORDER_STREAMS", 0u), 4u);
+            const bool early_totals = n_os == 0 && env_u32("KG_EARLY_TOTALS", 1u) != 0;     // (every chunk's ordering on stream3: in order behind every verify pass)
             for (uint32_t k = 0; k < n_os; k++)
                 if (!t->ostream[k]) {
                     int pr_least = 0, pr_greatest = 0;
@@ -1215,6 +1216,17 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                     hipLaunchKernelGGL(kg::chunk_base_kernel, dim3(1), dim3(1), 0, s3, ctot_c, base_c,
                                        c + 1 == n_chunks_p ? d_totals : (uint64_t *)nullptr);
                     if (n_os) HIP_TRY(hipEventRecord(t->pev[32 + c], s3));
+                    if (early_totals && c + 1 == n_chunks_p) {
+                        // Everything the host wants to know about this attempt is final here -- the list cursors (the last verify
+                        // pass is behind us on this stream), the overflow counters, the exact hit total (chunk_base_kernel just
+                        // above): it is sent now, and the host reads it, makes the aggregation's allocations and enqueues its
+                        // kernels while the last chunk's partition passes and placement still run (the round trip was ~70 us
+                        // of every scan, behind the ordering).
+                        HIP_TRY(hipMemcpyAsync(t->h_pin, d_pc, 48 * 8, hipMemcpyDeviceToHost, s3));
+                        HIP_TRY(hipMemcpyAsync(t->h_pin + 48, d_ovfc, 8 * kMaxChunks * 4, hipMemcpyDeviceToHost, s3));
+                        HIP_TRY(hipMemcpyAsync(t->h_pin + 80, d_totals, 48, hipMemcpyDeviceToHost, s3));
+                        HIP_TRY(hipEventRecord(t->pev[19], s3));
+                    }
                     hipLaunchKernelGGL((kg::hit_partition_kernel<true>), dim3(ogrid), dim3(kg::kHThreads), 0, s3, ulist_c, cused_c, ucur_c, ucap,
                                        gbase_c, n_groups, g0, 6u + gshift, gcur1_c, sortA_c, ucap, gtile_c);
                     hipLaunchKernelGGL((kg::hit_partition_kernel<false>), dim3(ogrid), dim3(kg::kHThreads), 0, s3, sortA_c, cused_c, ucur_c, ucap,
@@ -1242,10 +1254,14 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
             const uint32_t *h_ovf = reinterpret_cast<const uint32_t *>(t->h_pin + 48);
             static_assert(8 * kMaxChunks * 4 <= 32 * 8, "overflow counters must fit their pinned words");
             HIP_TRY(hipEventRecord(t->ev[2], t->stream));                 // end of the scan stage (of this attempt)
-            HIP_TRY(hipMemcpyAsync(t->h_pin, d_pc, 48 * 8, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipMemcpyAsync(t->h_pin + 48, d_ovfc, 8 * kMaxChunks * 4, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipMemcpyAsync(t->h_pin + 80, d_totals, 48, hipMemcpyDeviceToHost, t->stream));   // pinned: one host round trip for all three
-            HIP_TRY(hipStreamSynchronize(t->stream));
+            if (early_totals) {
+                HIP_TRY(hipEventSynchronize(t->pev[19]));                 // (the ordering of the last chunk may still be running)
+            } else {
+                HIP_TRY(hipMemcpyAsync(t->h_pin, d_pc, 48 * 8, hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipMemcpyAsync(t->h_pin + 48, d_ovfc, 8 * kMaxChunks * 4, hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipMemcpyAsync(t->h_pin + 80, d_totals, 48, hipMemcpyDeviceToHost, t->stream));   // pinned: one host round trip for all three
+                HIP_TRY(hipStreamSynchronize(t->stream));
+            }
             for (int k = 0; k < 6; k++) h_tot[k] = t->h_pin[80 + k];
             uint64_t need_u = 0, need_c = 0;
             uint32_t max_ovf = 0, guard = 0;
@@ -1261,6 +1277,8 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
                         attempt, n_chunks_p, (unsigned long long)max_chunk, (unsigned long long)nblocks, max_ovf, ovf_cap,
                         (unsigned long long)need_u, (unsigned long long)ucap, (unsigned long long)need_c, (unsigned long long)ccap,
                         (unsigned long long)n_regions_total, cap, part_buckets, part_shift, n_wg, (unsigned long long)h_pc[16 + n_chunks_p], use_bidx ? "byte home index" : "tags");
+            const bool redo = guard || max_ovf > ovf_cap || need_u > ucap || need_c > ccap;
+            if (redo && early_totals) HIP_TRY(hipStreamSynchronize(t->stream));   // the attempt is thrown away: its last kernels first
             if (guard) { too_skewed = true; st.fallback = 2; break; }    // the scatter pass's spin guard fired: direct path
             if (max_ovf > ovf_cap) { too_skewed = true; st.fallback = 1; break; }   // more overflow than provisioned: direct path
             n_hits = h_pc[16 + n_chunks_p];
@@ -1352,8 +1370,9 @@ int scan_impl(kg_table *t, const kg_params *p, const uint8_t *d_seq, const uint8
         st.scan_launches++;
         if ((rc = prefix_sum(t, d_counts, n_rows, d_offs, d_partial, d_totals))) return rc;
         uint64_t h_tot[6] = {0, 0, 0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(h_tot, d_totals, 48, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->h_pin + 80, d_totals, 48, hipMemcpyDeviceToHost, t->stream));    // (pinned words: no staging copy on the host)
         HIP_TRY(hipStreamSynchronize(t->stream));
+        for (int k = 0; k < 6; k++) h_tot[k] = t->h_pin[80 + k];
         n_hits = n_rows ? h_tot[0] : 0;
         st.windows_valid = counters ? (int64_t)h_tot[2] : -1;
         st.slots_inspected = counters ? (int64_t)h_tot[3] : -1;
